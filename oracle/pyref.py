@@ -1,0 +1,774 @@
+"""CPU restatement (Python big-int) of the han0110/learn-fhe ring hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing outside ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
+(``learn-fhe_amd/``) never routes through it.
+
+Every function cites the reference file:line (paths relative to the reference
+tree) whose arithmetic it restates.  Polynomials are plain Python lists of ints
+in [0, q); the modulus travels next to the list (the reference's ``Zq`` carries
+``q`` in every element, util/src/zq.rs:21-26).
+
+PARITY STATUS.  The reference (Rust) cannot be built or run in this
+environment and its tests hold no fixed vectors (all inputs are
+``thread_rng()``), so:
+  * results that are mathematically unique -- negacyclic products, external
+    products, key switches, rescales, blind rotations given the digits --
+    are pinned by the reference's own test properties (NTT product ==
+    schoolbook, util/src/ring/fft/zq.rs:107-116; round trip, 95-104; CRT
+    reconstruction preserved, util/src/ring/rns.rs:373-386);
+  * the forward-NTT *output order / choice of root* and the *digit values* of
+    ``decompose`` are pinned only by following the source line by line:
+    for those two, PARITY UNPINNED (restatement only, cross-checked between
+    this file and the independent C restatement in oracle/ref_ring.c).
+"""
+from __future__ import annotations
+
+import math
+
+U64 = (1 << 64) - 1
+
+# --------------------------------------------------------------------------------------
+# Zq scalar  (util/src/zq.rs)
+# --------------------------------------------------------------------------------------
+
+
+def zq_add(q, a, b):
+    """util/src/zq.rs:164-170 -- (a + b) as u128 % q."""
+    return (a + b) % q
+
+
+def zq_neg(q, a):
+    """util/src/zq.rs:146-153 -- from_u64(q, q - v) (so -0 == 0)."""
+    return (q - a) % q
+
+
+def zq_sub(q, a, b):
+    """util/src/zq.rs:172-178 -- a + (-b)."""
+    return (a + ((q - b) % q)) % q
+
+
+def zq_mul(q, a, b):
+    """util/src/zq.rs:180-186 -- (a * b) as u128 % q."""
+    return (a * b) % q
+
+
+def zq_from_i64(q, v):
+    """util/src/zq.rs:54-57 -- rem_euclid."""
+    return v % q
+
+
+def zq_to_i64(q, v):
+    """util/src/zq.rs:71-77."""
+    return v if v < (q >> 1) else v - q
+
+
+def zq_to_center_u64(q, v):
+    """util/src/zq.rs:83-89 -- two's-complement centred representative."""
+    return v if v < (q >> 1) else ((~(q - v)) + 1) & U64
+
+
+def zq_pow(q, v, e):
+    """util/src/zq.rs:111-117 -- BigUint::modpow."""
+    return pow(v, e, q)
+
+
+def zq_inv(q, v):
+    """util/src/zq.rs:123-126 -- extended gcd; the inverse mod q is unique."""
+    assert v != 0
+    return pow(v, -1, q)
+
+
+def f64_round(x: float) -> float:
+    """Rust f64::round: half away from zero (used at zq.rs:60, 128-140, rns.rs:340)."""
+    a = abs(x)
+    fl = math.floor(a)
+    if a - fl >= 0.5:
+        fl += 1
+    return math.copysign(float(fl), x)
+
+
+def _sat_i64(x: float) -> int:
+    """Rust `f64 as i64` saturating cast."""
+    if x != x:
+        return 0
+    if x >= 9.223372036854775807e18:
+        return (1 << 63) - 1
+    if x <= -9.223372036854775808e18:
+        return -(1 << 63)
+    return int(x)
+
+
+def _sat_u64(x: float) -> int:
+    if x != x or x <= 0:
+        return 0
+    if x >= 1.8446744073709552e19:
+        return U64
+    return int(x)
+
+
+def zq_from_f64(q, x: float):
+    """util/src/zq.rs:59-61."""
+    return zq_from_i64(q, _sat_i64(f64_round(x)))
+
+
+def zq_mod_switch(q, v, q_prime):
+    """util/src/zq.rs:128-130 -- f64 arithmetic, round half away."""
+    return zq_from_f64(q_prime, (float(v) * float(q_prime)) / float(q))
+
+
+def zq_mod_switch_odd(q, v, q_prime):
+    """util/src/zq.rs:132-140."""
+    x = (float(v) * float(q_prime)) / float(q)
+    u = math.floor(x)
+    if u == 0.0:
+        return _sat_u64(f64_round(x)) % q_prime
+    return (_sat_u64(u) | 1) % q_prime
+
+
+def is_prime(n: int) -> bool:
+    """util/src/zq.rs:337-342 calls num-bigint-dig 0.8.4 probably_prime(n, 20);
+    for u64 inputs a deterministic Miller-Rabin gives the same predicate."""
+    if n < 2:
+        return False
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+    for p in small:
+        if n % p == 0:
+            return n == p
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in small:
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def two_adic_primes(bits: int, log_n: int):
+    """util/src/zq.rs:325-329 -- descending scan of k*2^log_n + 1."""
+    assert bits > log_n
+    lo, hi = 1 << (bits - log_n - 1), 1 << (bits - log_n)
+    for k in range(hi - 1, lo - 1, -1):
+        c = (k << log_n) + 1
+        if is_prime(c):
+            yield c
+
+
+def generator(q):
+    """util/src/zq.rs:99-105 -- smallest g with g^((q-1)/2) == q-1."""
+    order = q - 1
+    for g in range(1, order):
+        if pow(g, order >> 1, q) == order:
+            return g
+    raise ValueError("no generator")
+
+
+def two_adic_generator(q, log_n):
+    """util/src/zq.rs:107-109."""
+    return pow(generator(q), (q - 1) >> log_n, q)
+
+
+# --------------------------------------------------------------------------------------
+# bit reversal, twiddles, NTT  (util/src/misc.rs:29-42, util/src/ring/fft.rs, fft/zq.rs)
+# --------------------------------------------------------------------------------------
+
+
+def bit_reverse(values):
+    """util/src/misc.rs:29-42 -- in-place bit-reversal permutation; no-op for len <= 2."""
+    n = len(values)
+    if n > 2:
+        assert n & (n - 1) == 0
+        log_len = n.bit_length() - 1
+        for i in range(n):
+            j = int(format(i, "0%db" % log_len)[::-1], 2)
+            if i < j:
+                values[i], values[j] = values[j], values[i]
+    return values
+
+
+_TW_CACHE: dict = {}
+
+
+def compute_twiddle(q):
+    """util/src/ring/fft/zq.rs:58-67.  s = trailing_zeros(q-1); omega of order 2^s;
+    2^(s-1) powers and their inverses, both bit-reversed over s-1 bits."""
+    order = q - 1
+    s = (order & -order).bit_length() - 1
+    w = two_adic_generator(q, s)
+    tw, x = [], 1
+    for _ in range(1 << (s - 1)):
+        tw.append(x)
+        x = x * w % q
+    twi = [zq_inv(q, v) for v in tw]
+    return bit_reverse(tw), bit_reverse(twi)
+
+
+def twiddle(q):
+    """util/src/ring/fft/zq.rs:49-56 -- only primes get a table (missing key panics)."""
+    if q not in _TW_CACHE:
+        if not is_prime(q):
+            raise KeyError("twiddle: q is not prime (reference panics, fft/zq.rs:44)")
+        _TW_CACHE[q] = compute_twiddle(q)
+    return _TW_CACHE[q]
+
+
+def nega_cyclic_ntt_in_place(q, a):
+    """util/src/ring/fft.rs:40-54 via fft/zq.rs:27-30; butterfly `dit` fft.rs:92-98.
+    Natural-order input -> bit-reversed-order output."""
+    tw, _ = twiddle(q)
+    n = len(a)
+    assert n & (n - 1) == 0
+    log_n = n.bit_length() - 1
+    for layer in range(log_n):
+        m, size = 1 << layer, 1 << (log_n - layer - 1)
+        for i in range(m):
+            t = tw[m + i]
+            base = 2 * size * i
+            for k in range(size):
+                u, v = a[base + k], a[base + size + k]
+                tb = t * v % q
+                a[base + k] = (u + tb) % q
+                a[base + size + k] = (u + ((q - tb) % q)) % q
+    return a
+
+
+def nega_cyclic_intt_in_place(q, a):
+    """util/src/ring/fft.rs:59-77 via fft/zq.rs:32-36; butterfly `dif` fft.rs:100-106."""
+    _, twi = twiddle(q)
+    n = len(a)
+    assert n & (n - 1) == 0
+    log_n = n.bit_length() - 1
+    n_inv = zq_inv(q, n % q)
+    for layer in range(log_n - 1, -1, -1):
+        m, size = 1 << layer, 1 << (log_n - layer - 1)
+        for i in range(m):
+            t = twi[m + i]
+            base = 2 * size * i
+            for k in range(size):
+                u, v = a[base + k], a[base + size + k]
+                a[base + k] = (u + v) % q
+                a[base + size + k] = ((u + ((q - v) % q)) % q) * t % q
+    for i in range(n):
+        a[i] = a[i] * n_inv % q
+    return a
+
+
+def nega_cyclic_ntt(q, a):
+    return nega_cyclic_ntt_in_place(q, list(a))
+
+
+def nega_cyclic_intt(q, a):
+    return nega_cyclic_intt_in_place(q, list(a))
+
+
+def nega_cyclic_ntt_mul(q, a, b):
+    """util/src/ring/fft/zq.rs:14-19."""
+    fa = nega_cyclic_ntt(q, a)
+    fb = nega_cyclic_ntt(q, b)
+    return nega_cyclic_intt_in_place(q, [x * y % q for x, y in zip(fa, fb)])
+
+
+def nega_cyclic_schoolbook_mul(q, a, b):
+    """util/src/ring.rs:421-440 -- the reference tests' own ground truth."""
+    n = len(a)
+    c = [x * b[0] % q for x in a]
+    for i, ai in enumerate(a):
+        for j in range(1, n):
+            p = ai * b[j] % q
+            if i + j < n:
+                c[i + j] = (c[i + j] + p) % q
+            else:
+                c[i + j - n] = (c[i + j - n] + (q - p) % q) % q
+    return c
+
+
+def rq_mul(q, a, b):
+    """util/src/ring.rs:256-264 -- prime q -> NTT product.  (Non-prime q goes to
+    Karatsuba in the reference; mathematically that is the schoolbook product.)"""
+    assert len(a) == len(b)
+    if is_prime(q) and (q - 1) % (2 * len(a)) == 0:
+        return nega_cyclic_ntt_mul(q, a, b)
+    return nega_cyclic_schoolbook_mul(q, a, b)
+
+
+def poly_add(q, a, b):
+    return [(x + y) % q for x, y in zip(a, b)]
+
+
+def poly_sub(q, a, b):
+    return [zq_sub(q, x, y) for x, y in zip(a, b)]
+
+
+def poly_neg(q, a):
+    return [zq_neg(q, x) for x in a]
+
+
+# --------------------------------------------------------------------------------------
+# automorphism, monomial multiply  (util/src/avec.rs:34-50, util/src/ring.rs:299-313)
+# --------------------------------------------------------------------------------------
+
+
+def automorphism(q, a, t):
+    """util/src/avec.rs:34-50 -- X -> X^t, t taken mod 2N."""
+    n = len(a)
+    assert n & (n - 1) == 0
+    t = t % (2 * n)
+    v = list(a)
+    for i in range(n):
+        it = (i * t) % (2 * n)
+        if it < n:
+            v[it] = a[i]
+        else:
+            v[it - n] = zq_neg(q, a[i])
+    return v
+
+
+def monomial_mul(q, a, k):
+    """util/src/ring.rs:299-313 -- multiply by X^k, k taken mod 2N."""
+    n = len(a)
+    i = k % (2 * n)
+    r = i % n
+    out = a[n - r:] + a[:n - r] if r else list(a)  # rotate_right(r)
+    if i < n:
+        for j in range(i):
+            out[j] = zq_neg(q, out[j])
+    else:
+        for j in range(i - n, n):
+            out[j] = zq_neg(q, out[j])
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# gadget decomposition  (util/src/misc/decompose.rs)
+# --------------------------------------------------------------------------------------
+
+
+class Base2Decomposor:
+    """util/src/misc/decompose.rs:6-64 (Zq flavour)."""
+
+    def __init__(self, q, log_b, d):
+        self.q = q
+        # q.next_power_of_two().ilog2()
+        self.log_q = (q - 1).bit_length() if q > 1 else 0
+        self.log_b = log_b
+        self.d = d
+        self.rounding_bits = max(self.log_q - log_b * d, 0)
+        self.bases = [(1 << (self.rounding_bits + j * log_b)) % q for j in range(d)]
+
+    def log_bases(self):
+        return [self.rounding_bits + j * self.log_b for j in range(self.d)]
+
+    def power_up_i64(self, v):
+        """decompose.rs:35-40 applied to an AVec<i64> (avec.rs:298-321): base * v_i."""
+        q = self.q
+        return [[base * zq_from_i64(q, x) % q for x in v] for base in self.bases]
+
+    def power_up_poly(self, v):
+        q = self.q
+        return [[base * x % q for x in v] for base in self.bases]
+
+    def decompose_scalar(self, v):
+        """decompose.rs:42-46, 91-112 -- rounding_shr then d signed digits."""
+        q, log_b = self.q, self.log_b
+        bits = self.rounding_bits
+        rounded = (v + (((1 << bits) >> 1) % q)) % q
+        v = (rounded >> bits) % q
+        b_by_2, mask, neg_b = 1 << (log_b - 1), (1 << log_b) - 1, q - (1 << log_b)
+        c = zq_to_center_u64(q, v)
+        out = []
+        for _ in range(self.d):
+            limb = c & mask
+            carry = 1 if (limb + (c & 1)) > b_by_2 else 0
+            c >>= log_b
+            c = (c + carry) & U64
+            out.append((limb + carry * neg_b) % q)
+        return out
+
+    def decompose(self, poly):
+        """decompose.rs:137-155 -- d polynomials, least-significant digit first."""
+        digs = [self.decompose_scalar(v) for v in poly]
+        return [[digs[i][j] for i in range(len(poly))] for j in range(self.d)]
+
+
+# --------------------------------------------------------------------------------------
+# RLWE / RGSW  (scheme/fhew/src/rlwe.rs, rgsw.rs)
+# --------------------------------------------------------------------------------------
+
+
+def dot_polys(q, keys, limbs):
+    """util/src/misc.rs:44-62 -- sum_j keys[j] * limbs[j] (negacyclic products)."""
+    assert len(keys) == len(limbs)
+    acc = None
+    for k, l in zip(keys, limbs):
+        p = rq_mul(q, k, l)
+        acc = p if acc is None else poly_add(q, acc, p)
+    return acc
+
+
+def rlwe_key_switch(q, dec: Base2Decomposor, ksk_a, ksk_b, ct_a, ct_b):
+    """scheme/fhew/src/rlwe.rs:177-186."""
+    limbs = dec.decompose(ct_a)
+    a = dot_polys(q, ksk_a, limbs)
+    b = poly_add(q, dot_polys(q, ksk_b, limbs), ct_b)
+    return a, b
+
+
+def rlwe_automorphism(q, dec, t, ak_a, ak_b, ct_a, ct_b):
+    """scheme/fhew/src/rlwe.rs:188-191 (+ 80-82)."""
+    return rlwe_key_switch(q, dec, ak_a, ak_b, automorphism(q, ct_a, t), automorphism(q, ct_b, t))
+
+
+def rgsw_external_product(q, dec, rgsw_a, rgsw_b, ct_a, ct_b):
+    """scheme/fhew/src/rgsw.rs:116-128 -- limbs = decompose(a) ++ decompose(b)."""
+    limbs = dec.decompose(ct_a) + dec.decompose(ct_b)
+    return dot_polys(q, rgsw_a, limbs), dot_polys(q, rgsw_b, limbs)
+
+
+def rgsw_internal_product(q, dec, ct0_a, ct0_b, ct1_a, ct1_b):
+    """scheme/fhew/src/rgsw.rs:130-150 -- the evaluation-domain user."""
+    e0a = [nega_cyclic_ntt(q, p) for p in ct0_a]
+    e0b = [nega_cyclic_ntt(q, p) for p in ct0_b]
+    out_a, out_b = [], []
+    for a1, b1 in zip(ct1_a, ct1_b):
+        limbs = [nega_cyclic_ntt(q, p) for p in dec.decompose(a1) + dec.decompose(b1)]
+
+        def edot(keys):
+            acc = None
+            for k, l in zip(keys, limbs):
+                p = [x * y % q for x, y in zip(k, l)]
+                acc = p if acc is None else poly_add(q, acc, p)
+            return nega_cyclic_intt_in_place(q, acc)
+
+        out_a.append(edot(e0a))
+        out_b.append(edot(e0b))
+    return out_a, out_b
+
+
+def rlwe_sample_extract(q, ct_a, ct_b, i):
+    """scheme/fhew/src/rlwe.rs:193-202."""
+    a = list(reversed(ct_a[: i + 1])) + [zq_neg(q, v) for v in reversed(ct_a[i + 1:])]
+    return a, ct_b[i]
+
+
+# ---- key material (test-side; sampling is not parity relevant) ------------------------
+
+
+def rlwe_sk_encrypt(q, sk_i64, pt, rng, noise=True):
+    """scheme/fhew/src/rlwe.rs:146-156 -- b = a*sk + e + pt."""
+    n = len(pt)
+    a = [rng.randrange(q) for _ in range(n)]
+    e = [zq_from_i64(q, rng.randint(-3, 3)) if noise else 0 for _ in range(n)]
+    sk = [zq_from_i64(q, s) for s in sk_i64]
+    b = poly_add(q, poly_add(q, rq_mul(q, a, sk), e), pt)
+    return a, b
+
+
+def rlwe_decrypt(q, sk_i64, ct_a, ct_b):
+    """scheme/fhew/src/rlwe.rs:172-175."""
+    sk = [zq_from_i64(q, s) for s in sk_i64]
+    return poly_sub(q, ct_b, rq_mul(q, ct_a, sk))
+
+
+def rlwe_ksk_gen(q, dec, sk0, sk1, rng):
+    """scheme/fhew/src/rlwe.rs:109-120 -- rows encrypt (-sk1) * base_j under sk0."""
+    rows = [rlwe_sk_encrypt(q, sk0, pt, rng) for pt in dec.power_up_i64([-s for s in sk1])]
+    return [r[0] for r in rows], [r[1] for r in rows]
+
+
+def sk_automorphism(sk, t):
+    """scheme/fhew/src/rlwe.rs:37-39 on AVec<i64> (avec.rs:34-50)."""
+    n = len(sk)
+    t = t % (2 * n)
+    v = list(sk)
+    for i in range(n):
+        it = (i * t) % (2 * n)
+        if it < n:
+            v[it] = sk[i]
+        else:
+            v[it - n] = -sk[i]
+    return v
+
+
+def rlwe_ak_gen(q, dec, t, sk, rng):
+    """scheme/fhew/src/rlwe.rs:122-132."""
+    return rlwe_ksk_gen(q, dec, sk, sk_automorphism(sk, t), rng)
+
+
+def rgsw_encrypt(q, dec, sk, pt, rng):
+    """scheme/fhew/src/rgsw.rs:84-105 -- 2d RLWE zeros; rows 0..d get pt*base on a, d..2d on b."""
+    n, d = len(pt), dec.d
+    pts = dec.power_up_poly(pt)
+    rows = [rlwe_sk_encrypt(q, sk, [0] * n, rng) for _ in range(2 * d)]
+    a = [r[0] for r in rows]
+    b = [r[1] for r in rows]
+    for j in range(d):
+        a[j] = poly_add(q, a[j], pts[j])
+        b[d + j] = poly_add(q, b[d + j], pts[j])
+    return a, b
+
+
+# --------------------------------------------------------------------------------------
+# LWE  (scheme/fhew/src/lwe.rs)
+# --------------------------------------------------------------------------------------
+
+
+def lwe_mod_switch(q, a, b, q_prime):
+    """scheme/fhew/src/lwe.rs:90-92."""
+    return [zq_mod_switch(q, v, q_prime) for v in a], zq_mod_switch(q, b, q_prime)
+
+
+def lwe_mod_switch_odd(q, a, b, q_prime):
+    """scheme/fhew/src/lwe.rs:94-99."""
+    return [zq_mod_switch_odd(q, v, q_prime) for v in a], zq_mod_switch_odd(q, b, q_prime)
+
+
+def lwe_key_switch(q, dec: Base2Decomposor, ksk_a, ksk_b, ct_a, ct_b):
+    """scheme/fhew/src/lwe.rs:151-160.  limbs flattened digit-major:
+    decompose(a) yields d vectors of len N; `.flatten()` -> index j*N + i."""
+    limbs = [x for poly in dec.decompose(ct_a) for x in poly]
+    assert len(limbs) == len(ksk_a)
+    n_out = len(ksk_a[0])
+    a = [0] * n_out
+    b = 0
+    for row_a, row_b, l in zip(ksk_a, ksk_b, limbs):
+        for k in range(n_out):
+            a[k] = (a[k] + row_a[k] * l) % q
+        b = (b + row_b * l) % q
+    return a, (b + ct_b) % q
+
+
+def lwe_sk_encrypt(q, sk, pt, rng, noise=True):
+    """scheme/fhew/src/lwe.rs:128-138."""
+    a = [rng.randrange(q) for _ in sk]
+    e = rng.randint(-3, 3) if noise else 0
+    b = (sum(x * zq_from_i64(q, s) for x, s in zip(a, sk)) + pt + e) % q
+    return a, b
+
+
+def lwe_decrypt(q, sk, a, b):
+    """scheme/fhew/src/lwe.rs:140-148."""
+    return (b - sum(x * zq_from_i64(q, s) for x, s in zip(a, sk))) % q
+
+
+def lwe_ksk_gen(q, dec, sk0, sk1, rng):
+    """scheme/fhew/src/lwe.rs:108-119 -- power_up(-sk1).flatten(): digit-major rows."""
+    rows = [lwe_sk_encrypt(q, sk0, pt, rng) for poly in dec.power_up_i64([-s for s in sk1]) for pt in poly]
+    return [r[0] for r in rows], [r[1] for r in rows]
+
+
+# --------------------------------------------------------------------------------------
+# FHEW / LMKCDEY blind rotation  (scheme/fhew/src/bootstrapping.rs)
+# --------------------------------------------------------------------------------------
+
+AUTO_G = 5  # scheme/fhew/src/rlwe.rs:93
+
+
+def ak_t(n, w):
+    """scheme/fhew/src/bootstrapping.rs:86-89 -- [-g, g^1 .. g^w] mod 2N (as i64 via Zq::into)."""
+    q2 = 2 * n
+    g = AUTO_G % q2
+    ts = [zq_to_i64(q2, (q2 - g) % q2)]
+    x = 1
+    for _ in range(w):
+        x = x * g % q2
+        ts.append(zq_to_i64(q2, x))
+    return ts
+
+
+def log_g_map(n, sign):
+    """scheme/fhew/src/bootstrapping.rs:228-231."""
+    q2 = 2 * n
+    g = AUTO_G % q2
+    out, x = {}, 1
+    for l in range(n // 2):
+        out[(x * sign) % q2] = l
+        x = x * g % q2
+    return out
+
+
+def i_minus_i_plus(n, a):
+    """scheme/fhew/src/bootstrapping.rs:212-226."""
+    lm, lp = log_g_map(n, -1), log_g_map(n, 1)
+    i_minus = [[] for _ in range(n // 2)]
+    i_plus = [[] for _ in range(n // 2)]
+    for i, ai in enumerate(a):
+        in_m, in_p = ai in lm, ai in lp
+        if in_m and not in_p:
+            i_minus[lm[ai]].append(i)
+        elif in_p and not in_m:
+            i_plus[lp[ai]].append(i)
+        elif ai == 0:
+            pass
+        else:
+            raise AssertionError("unreachable (bootstrapping.rs:221)")
+    return i_minus, i_plus
+
+
+def blind_rotate_schedule(n, w, a):
+    """The op sequence of scheme/fhew/src/bootstrapping.rs:172-209 as a list of
+    ('ep', j) (external product with brk[j]) and ('ak', v) (automorphism with ak[v])."""
+    i_minus, i_plus = i_minus_i_plus(n, a)
+    ops = []
+    v = 0
+    for l in range(len(i_minus) - 1, 0, -1):
+        for j in i_minus[l]:
+            ops.append(("ep", j))
+        v += 1
+        if i_minus[l - 1] or v == w or l == 1:
+            ops.append(("ak", v))
+            v = 0
+    for j in i_minus[0]:
+        ops.append(("ep", j))
+    ops.append(("ak", 0))
+    for l in range(len(i_plus) - 1, 0, -1):
+        for j in i_plus[l]:
+            ops.append(("ep", j))
+        v += 1
+        if i_plus[l - 1] or v == w or l == 1:
+            ops.append(("ak", v))
+            v = 0
+    for j in i_plus[0]:
+        ops.append(("ep", j))
+    return ops
+
+
+def blind_rotate_core(q, n, w, rgsw_dec, rlwe_dec, brk, ak, a, acc):
+    """scheme/fhew/src/bootstrapping.rs:172-209.
+    brk[j] = (rgsw_a, rgsw_b); ak[v] = (t, ksk_a, ksk_b)."""
+    acc_a, acc_b = acc
+    for kind, idx in blind_rotate_schedule(n, w, a):
+        if kind == "ep":
+            acc_a, acc_b = rgsw_external_product(q, rgsw_dec, brk[idx][0], brk[idx][1], acc_a, acc_b)
+        else:
+            t, ka, kb = ak[idx]
+            acc_a, acc_b = rlwe_automorphism(q, rlwe_dec, t, ka, kb, acc_a, acc_b)
+    return acc_a, acc_b
+
+
+def blind_rotate(q, n, w, rgsw_dec, rlwe_dec, brk, ak, f, lwe_a, lwe_b):
+    """scheme/fhew/src/bootstrapping.rs:158-169 -- f' = f.automorphism(-g) * X^(b*g); acc = (0, f').
+    (b: Zq mod 2N) * g is a Zq product mod 2N (zq.rs impl Mul<i64>), then X ^ Zq -> Monomial(to_i64)."""
+    q2 = 2 * n
+    bg = lwe_b * (AUTO_G % q2) % q2
+    f_prime = monomial_mul(q, automorphism(q, f, -AUTO_G), zq_to_i64(q2, bg))
+    return blind_rotate_core(q, n, w, rgsw_dec, rlwe_dec, brk, ak, lwe_a, ([0] * n, f_prime))
+
+
+# --------------------------------------------------------------------------------------
+# RNS  (util/src/ring/rns.rs) and CKKS key switch (scheme/ckks/src/ckks.rs:284-293)
+# --------------------------------------------------------------------------------------
+
+
+class Rns:
+    """util/src/ring/rns.rs:278-346."""
+
+    def __init__(self, qs, ps=()):
+        self.qs, self.ps = list(qs), list(ps)
+        self.q = math.prod(self.qs)
+        self.q_hats = [self.q // qi for qi in self.qs]
+        self.q_hats_inv_qs = [pow(h % qi, -1, qi) for qi, h in zip(self.qs, self.q_hats)]
+        self.q_fracs = [1.0 / float(qi) for qi in self.qs]
+        self.q_hats_ps = [[h % pj for h in self.q_hats] for pj in self.ps]
+        self.uq_ps = [[(self.q * u) % pj for u in range(len(self.qs) + 1)] for pj in self.ps]
+
+    def extend_bases(self, vqs):
+        """rns.rs:331-345 -- sequential f64 sum, round half away."""
+        vs = [v * inv % qi for v, inv, qi in zip(vqs, self.q_hats_inv_qs, self.qs)]
+        acc = None
+        for frac, vi in zip(self.q_fracs, vs):
+            term = frac * float(vi)
+            acc = term if acc is None else acc + term  # Iterator::sum::<f64>() starts at 0.0; 0.0 + x == x
+        u = int(f64_round(0.0 + acc))
+        out = []
+        for pj, hats, uq in zip(self.ps, self.q_hats_ps, self.uq_ps):
+            dot = None
+            for h, vi in zip(hats, vs):
+                term = h * (vi % pj) % pj  # `&Zq * &u64` -> from_u64 reduces vi mod p first (zq.rs:266-272)
+                dot = term if dot is None else (dot + term) % pj
+            out.append(zq_sub(pj, dot, uq[u]))
+        return out
+
+    def reconstruct(self, vqs):
+        """rns.rs:324-329 + centering_rem 354-365."""
+        v = sum(h * inv * x for h, inv, x in zip(self.q_hats, self.q_hats_inv_qs, vqs)) % self.q
+        return v if v < (self.q >> 1) else v - self.q
+
+
+def rns_extend_bases(qs, limbs, ps):
+    """util/src/ring/rns.rs:83-91 -- returns the K new p-limbs."""
+    rns = Rns(qs, ps)
+    n = len(limbs[0])
+    cols = [rns.extend_bases([limb[i] for limb in limbs]) for i in range(n)]
+    return [[cols[i][j] for i in range(n)] for j in range(len(ps))]
+
+
+def rns_rescale_k(qps, limbs, k):
+    """util/src/ring/rns.rs:103-118 (+ round 120-125, div 127-132)."""
+    assert k > 0
+    qs, ps = qps[: len(qps) - k], qps[len(qps) - k:]
+    p = math.prod(ps)
+    limbs = [[(v + (p >> 1) % qi) % qi for v in limb] for qi, limb in zip(qps, limbs)]
+    ql, pl = limbs[: len(qs)], limbs[len(qs):]
+    if k == 1:
+        rp = pl[0]
+        ql = [[zq_sub(qi, v, vp % qi) for v, vp in zip(limb, rp)] for qi, limb in zip(qs, ql)]
+    else:
+        sw = rns_extend_bases(ps, pl, qs)
+        ql = [poly_sub(qi, limb, s) for qi, limb, s in zip(qs, ql, sw)]
+    out = []
+    for qi, limb in zip(qs, ql):
+        p_inv = zq_inv(qi, p % qi)
+        out.append([v * p_inv % qi for v in limb])
+    return out
+
+
+def rns_mul(qs, a_limbs, b_limbs):
+    """util/src/ring/rns.rs:148-158 for equal bases."""
+    return [rq_mul(qi, a, b) for qi, a, b in zip(qs, a_limbs, b_limbs)]
+
+
+def ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a):
+    """scheme/ckks/src/ckks.rs:284-293.  ksk limbs over qs++ps; ct limbs over qs."""
+    qps = list(qs) + list(ps)
+    a_ext = list(ct_a) + rns_extend_bases(qs, ct_a, ps)
+    b = rns_rescale_k(qps, rns_mul(qps, ksk_b, a_ext), len(ps))
+    b = [poly_add(qi, x, y) for qi, x, y in zip(qs, b, ct_b)]
+    a = rns_rescale_k(qps, rns_mul(qps, ksk_a, a_ext), len(ps))
+    return b, a
+
+
+def ckks_primes(log_n, log_qi, big_l):
+    """scheme/ckks/src/ckks.rs:20-35."""
+    gen = two_adic_primes(log_qi, log_n + 1)
+    qs = [next(gen) for _ in range(big_l)]
+    ps = [next(gen) for _ in range(big_l)]
+    return qs, ps
+
+
+# --------------------------------------------------------------------------------------
+# deterministic input generator shared by oracle, tests and bench (SplitMix64)
+# --------------------------------------------------------------------------------------
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & U64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & U64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & U64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & U64
+        return z ^ (z >> 31)
+
+    def uniform(self, q, n):
+        """n values in [0,q): 64-bit draw mod q (bias irrelevant for test data)."""
+        return [self.next() % q for _ in range(n)]
