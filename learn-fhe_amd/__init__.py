@@ -1,0 +1,8 @@
+"""learn-fhe_amd: MI355X (gfx950) polynomial-ring backend for the FHE hot path of han0110/learn-fhe.
+
+The product is the C-ABI shared library `lib/libfhe_ring.so` (include/fhe_ring.h) built from the HIP
+sources in `csrc/`.  This Python package is only the harness-side binding used by tests and bench:
+it loads the library with ctypes and fails loudly if it is missing -- there is no CPU fallback.
+"""
+from ._lib import FheError, build, lib, lib_path  # noqa: F401
+from .ring import NttContext  # noqa: F401

@@ -1,0 +1,69 @@
+"""ctypes loader for lib/libfhe_ring.so.  Raises if the library is absent: no fallback of any kind."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libfhe_ring.so")
+_lib = None
+
+STATUS = {0: "FHE_OK", 1: "FHE_ERR_INVALID", 2: "FHE_ERR_NOT_PRIME", 3: "FHE_ERR_NO_ROOT", 4: "FHE_ERR_MODULUS",
+          5: "FHE_ERR_HIP", 6: "FHE_ERR_UNSUPPORTED", 7: "FHE_ERR_NO_DEVICE"}
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class FheError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        extra = ""
+        if code == 5 and _lib is not None:
+            extra = " (hipError %d)" % _lib.fhe_last_hip_error()
+        super().__init__("%s: %s%s" % (where, STATUS.get(code, str(code)), extra))
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+u64p = C.POINTER(C.c_uint64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise FileNotFoundError(
+                "%s not found: build it with `make -C learn-fhe_amd/csrc` (or __graft_entry__.build()); "
+                "there is no CPU fallback" % _SO)
+        L = C.CDLL(_SO)
+        L.fhe_version.restype = C.c_char_p
+        L.fhe_is_prime.argtypes = [C.c_uint64]
+        L.fhe_two_adic_primes.argtypes = [C.c_int, C.c_int, C.c_int, u64p]
+        L.fhe_ctx_create.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
+        L.fhe_ctx_destroy.argtypes = [C.c_void_p]
+        L.fhe_ctx_destroy.restype = None
+        L.fhe_ctx_info.argtypes = [C.c_void_p, u64p, C.POINTER(C.c_int), u64p, u64p]
+        L.fhe_ctx_twiddles.argtypes = [C.c_void_p, C.c_int, u64p, C.c_size_t]
+        for name in ("fhe_ntt_fwd", "fhe_ntt_inv"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.fhe_ntt_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.fhe_pointwise_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != 0:
+        raise FheError(rc, where)

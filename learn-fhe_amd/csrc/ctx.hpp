@@ -1,0 +1,28 @@
+// Per-modulus context: what the reference keeps in its global twiddle cache
+// (util/src/ring/fft/zq.rs:38-67), built once, immutable, plus the HBM copies the kernels read.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "dev_arith.hpp"
+#include "modmath.hpp"
+
+struct fhe_ctx {
+    uint64_t q = 0;
+    int s = 0;           // trailing_zeros(q - 1)
+    uint64_t g = 0;      // smallest quadratic non-residue
+    uint64_t omega = 0;  // g^((q-1) >> s), order 2^s
+    int log_cap = 0;     // tables hold 2^log_cap entries = min(2^(s-1), 2^FHE_MAX_LOG_N)
+    std::vector<uint64_t> tw, twi;  // reference layout: entry j = omega^(+-bitrev_{s-1}(j))
+    uint64_t ninv[32] = {0}, ninv_s[32] = {0};  // (2^k)^-1 mod q and its Shoup companion
+    fhe::Barrett barrett{};
+    int device = -1;
+    fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM
+};
+
+namespace fhe {
+constexpr int MAX_LOG_N = 17;
+int ctx_build_host(uint64_t q, fhe_ctx *c);  // returns FHE_* status
+}  // namespace fhe

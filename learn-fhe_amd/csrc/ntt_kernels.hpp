@@ -1,0 +1,241 @@
+// Batched negacyclic NTT / inverse NTT kernels for gfx950 (MI355X).
+//
+// One polynomial is owned by T = N / E threads (E = 2^LOG_E coefficients per thread, kept in
+// registers); PPW polynomials share a workgroup when N is small.  The log2(N) butterfly layers are
+// cut into passes of up to LOG_E layers; inside a pass a thread owns complete radix-2^R butterfly
+// groups, so the layers of a pass run entirely in registers.  Between passes the coefficients are
+// exchanged through an LDS image of the polynomial (padded by one 8-byte slot per 16 coefficients,
+// which makes the strided pass patterns bank-conflict free for ds_read/write_b64).  HBM is touched
+// exactly once per coefficient per direction: 16*N algorithmic bytes per transform.
+//
+// Layer/twiddle order follows the reference exactly (util/src/ring/fft.rs:40-77): forward =
+// Cooley-Tukey layers 0..logN-1 with twiddle tw[2^layer + i], natural in / bit-reversed out;
+// inverse = Gentleman-Sande layers logN-1..0 with twi[2^layer + i], then * n^-1.
+#pragma once
+#include <type_traits>
+
+#include "dev_arith.hpp"
+
+namespace fhe {
+
+template <int LOG_N, int LOG_E, int PPW>
+struct NttCfg {
+    static constexpr int N = 1 << LOG_N;
+    static constexpr int E = 1 << LOG_E;
+    static constexpr int T = N / E;                             // threads per polynomial
+    static constexpr int THREADS = T * PPW;                     // workgroup size
+    static constexpr int P = (LOG_N + LOG_E - 1) / LOG_E;       // number of passes
+    static constexpr int R0 = LOG_N - (P - 1) * LOG_E;          // layers in the short pass (layers 0..R0-1)
+    static constexpr int PN = N + (N >> 4);                     // padded LDS image, in u64
+    static constexpr size_t LDS_BYTES = (P > 1) ? size_t(PN) * PPW * 8 : 0;
+    static_assert(LOG_E >= 1 && LOG_E <= LOG_N, "bad LOG_E");
+    static_assert(THREADS >= 1 && THREADS <= 1024, "bad workgroup size");
+};
+
+__device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }
+
+template <int I, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, END>(f);
+    }
+}
+
+// element index of register r of butterfly group `grp` in the pass that covers layers [L0, L0+R)
+template <int LOG_N, int L0, int R>
+__device__ __forceinline__ int pass_index(int grp, int r) {
+    constexpr int h = LOG_N - L0 - R;
+    const int top = grp >> h, low = grp & ((1 << h) - 1);
+    return (top << (h + R)) | (r << h) | low;
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-register radix-2^R passes on x[OFF .. OFF + 2^R)
+// ---------------------------------------------------------------------------------------------
+template <int L0, int R, int OFF, int E>
+__device__ __forceinline__ void fwd_pass_regs(u64 (&x)[E], int top, const TwPair *__restrict__ tw, u64 q, u64 q2) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int half = 1 << (R - 1 - k);
+#pragma unroll
+        for (int b = 0; b < (1 << k); ++b) {
+            const TwPair p = tw[(1 << (L0 + k)) + (top << k) + b];
+#pragma unroll
+            for (int j = 0; j < half; ++j) ct_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
+        }
+    }
+}
+
+template <int L0, int R, int OFF, int E>
+__device__ __forceinline__ void inv_pass_regs(u64 (&x)[E], int top, const TwPair *__restrict__ twi, u64 q, u64 q2) {
+#pragma unroll
+    for (int k = R - 1; k >= 0; --k) {
+        const int half = 1 << (R - 1 - k);
+#pragma unroll
+        for (int b = 0; b < (1 << k); ++b) {
+            const TwPair p = twi[(1 << (L0 + k)) + (top << k) + b];
+#pragma unroll
+            for (int j = 0; j < half; ++j) gs_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
+        }
+    }
+}
+
+// wave-uniform `top` can be moved to an SGPR so the twiddle loads become scalar loads
+template <int LOG_N, int L0, int R, int T>
+__device__ __forceinline__ int pass_top(int grp) {
+    constexpr int h = LOG_N - L0 - R;
+    int top = grp >> h;
+    if constexpr (h >= 6 && T >= 64) top = __builtin_amdgcn_readfirstlane(top);
+    return top;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward transform: passes run L0 = 0, R0, R0+LOG_E, ...
+// ---------------------------------------------------------------------------------------------
+template <typename C, int LOG_N, int LOG_E, int L0>
+__device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
+                                        const TwPair *__restrict__ tw, u64 q, u64 q2) {
+    constexpr int E = 1 << LOG_E;
+    constexpr int R = (L0 == 0) ? C::R0 : LOG_E;
+    constexpr int G = E >> R;  // butterfly groups per thread in this pass
+    constexpr bool first = (L0 == 0), last = (L0 + R == LOG_N);
+    // load
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+        const int grp = t + C::T * gg;
+#pragma unroll
+        for (int r = 0; r < (1 << R); ++r) {
+            const int i = pass_index<LOG_N, L0, R>(grp, r);
+            if constexpr (first) x[gg * (1 << R) + r] = active ? g[i] : 0;
+            else x[gg * (1 << R) + r] = lds[lds_phys(i)];
+        }
+    }
+    // butterflies
+    static_for<0, G>([&](auto gg_c) {
+        constexpr int gg = decltype(gg_c)::value;
+        const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
+        fwd_pass_regs<L0, R, gg * (1 << R), E>(x, top, tw, q, q2);
+    });
+    // store
+    if constexpr (last && C::P == 1) {
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int r = 0; r < (1 << R); ++r)
+                if (active) g[pass_index<LOG_N, L0, R>(t + C::T * gg, r)] = canon4(x[gg * (1 << R) + r], q, q2);
+    } else {
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int r = 0; r < (1 << R); ++r) {
+                u64 v = x[gg * (1 << R) + r];
+                if constexpr (last) v = canon4(v, q, q2);
+                lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = v;
+            }
+        __syncthreads();
+        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R>(x, t, g, lds, active, tw, q, q2);
+    }
+}
+
+template <int LOG_N, int LOG_E, int PPW>
+__global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_kernel(
+    u64 *__restrict__ data, const TwPair *__restrict__ tw, u64 q, unsigned batch) {
+    using C = NttCfg<LOG_N, LOG_E, PPW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
+    const unsigned poly = blockIdx.x * PPW + pw;
+    const bool active = poly < batch;
+    u64 *g = data + size_t(poly) * C::N;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
+    u64 x[C::E];
+    const u64 q2 = 2 * q;
+    fwd_run<C, LOG_N, LOG_E, 0>(x, t, g, lds, active, tw, q, q2);
+    if constexpr (C::P > 1) {
+        // the canonical image sits in LDS: stream it out with consecutive lanes on consecutive addresses
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < C::E; ++k) {
+                const int i = t + C::T * k;
+                g[i] = lds[lds_phys(i)];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse transform: passes run from the last layers back to layer 0
+// ---------------------------------------------------------------------------------------------
+template <typename C, int LOG_N, int LOG_E, int LEND>  // this pass covers layers [L0, LEND)
+__device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
+                                        const TwPair *__restrict__ twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
+    constexpr int E = 1 << LOG_E;
+    constexpr int R = (LEND == C::R0) ? C::R0 : LOG_E;
+    constexpr int L0 = LEND - R;
+    constexpr int G = E >> R;
+    constexpr bool final_pass = (L0 == 0);
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+        const int grp = t + C::T * gg;
+#pragma unroll
+        for (int r = 0; r < (1 << R); ++r) {
+            const int i = pass_index<LOG_N, L0, R>(grp, r);
+            if constexpr (C::P == 1) x[gg * (1 << R) + r] = active ? g[i] : 0;
+            else x[gg * (1 << R) + r] = lds[lds_phys(i)];
+        }
+    }
+    static_for<0, G>([&](auto gg_c) {
+        constexpr int gg = decltype(gg_c)::value;
+        const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
+        inv_pass_regs<L0, R, gg * (1 << R), E>(x, top, twi, q, q2);
+    });
+    if constexpr (final_pass) {
+        // * n^-1 (util/src/ring/fft.rs:76), canonicalise, store: consecutive lanes -> consecutive addresses
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int r = 0; r < (1 << R); ++r) {
+                const u64 v = csub(mul_shoup_lazy(x[gg * (1 << R) + r], ninv, ninv_s, q), q);
+                if (active) g[pass_index<LOG_N, L0, R>(t + C::T * gg, r)] = v;
+            }
+    } else {
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int r = 0; r < (1 << R); ++r)
+                lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = x[gg * (1 << R) + r];
+        __syncthreads();
+        inv_run<C, LOG_N, LOG_E, L0>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+    }
+}
+
+template <int LOG_N, int LOG_E, int PPW>
+__global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_kernel(
+    u64 *__restrict__ data, const TwPair *__restrict__ twi, u64 q, unsigned batch, u64 ninv, u64 ninv_s) {
+    using C = NttCfg<LOG_N, LOG_E, PPW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
+    const unsigned poly = blockIdx.x * PPW + pw;
+    const bool active = poly < batch;
+    u64 *g = data + size_t(poly) * C::N;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
+    u64 x[C::E];
+    const u64 q2 = 2 * q;
+    if constexpr (C::P > 1) {
+#pragma unroll
+        for (int k = 0; k < C::E; ++k) {
+            const int i = t + C::T * k;
+            lds[lds_phys(i)] = active ? g[i] : 0;
+        }
+        __syncthreads();
+    }
+    inv_run<C, LOG_N, LOG_E, LOG_N>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+}
+
+// a[i] <- a[i] * b[i] mod q (evaluation-domain product, util/src/ring.rs:266-270)
+__global__ void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t len, Barrett B) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < len; i += size_t(gridDim.x) * blockDim.x)
+        a[i] = mulmod_barrett(a[i], b[i], B);
+}
+
+}  // namespace fhe

@@ -1,0 +1,328 @@
+// extern "C" entry points declared in include/fhe_ring.h: context set-up and the transform launches.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "../../include/fhe_ring.h"
+#include "ctx.hpp"
+#include "ntt_kernels.hpp"
+
+using fhe::u64;
+
+namespace {
+thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                         \
+    do {                                      \
+        hipError_t e_ = (expr);               \
+        if (e_ != hipSuccess) {               \
+            g_last_hip = (int)e_;             \
+            return FHE_ERR_HIP;               \
+        }                                     \
+    } while (0)
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline int ilog2(size_t n) { return 63 - __builtin_clzll((unsigned long long)n); }
+
+// validates (ctx, n) the way the reference would panic
+int check_transform(const fhe_ctx *ctx, const void *a, size_t n) {
+    if (!ctx || !a || !is_pow2(n)) return FHE_ERR_INVALID;
+    if (n == 1) return FHE_OK;
+    int log_n = ilog2(n);
+    if (log_n > ctx->s - 1) return FHE_ERR_NO_ROOT;
+    if (log_n > ctx->log_cap) return FHE_ERR_UNSUPPORTED;
+    return FHE_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <int LOG_N, int LOG_E, int PPW>
+int launch_fwd(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
+    using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
+    auto k = fhe::ntt_fwd_kernel<LOG_N, LOG_E, PPW>;
+    if (C::LDS_BYTES > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    unsigned grid = (unsigned)((batch + PPW - 1) / PPW);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, c->d_tw, (u64)c->q, (unsigned)batch);
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
+}
+
+template <int LOG_N, int LOG_E, int PPW>
+int launch_inv(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
+    using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
+    auto k = fhe::ntt_inv_kernel<LOG_N, LOG_E, PPW>;
+    if (C::LDS_BYTES > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    unsigned grid = (unsigned)((batch + PPW - 1) / PPW);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, c->d_twi, (u64)c->q, (unsigned)batch,
+                       (u64)c->ninv[LOG_N], (u64)c->ninv_s[LOG_N]);
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
+}
+
+// (LOG_N -> LOG_E, PPW): 16 coefficients per thread from N = 128 up; small rings pack many polynomials
+// into one 64..256-thread workgroup
+#define NTT_DISPATCH(FN, log_n, ...)                          \
+    switch (log_n) {                                          \
+        case 1: return FN<1, 1, 64>(__VA_ARGS__);             \
+        case 2: return FN<2, 2, 64>(__VA_ARGS__);             \
+        case 3: return FN<3, 3, 64>(__VA_ARGS__);             \
+        case 4: return FN<4, 4, 64>(__VA_ARGS__);             \
+        case 5: return FN<5, 3, 16>(__VA_ARGS__);             \
+        case 6: return FN<6, 3, 16>(__VA_ARGS__);             \
+        case 7: return FN<7, 4, 16>(__VA_ARGS__);             \
+        case 8: return FN<8, 4, 16>(__VA_ARGS__);             \
+        case 9: return FN<9, 4, 8>(__VA_ARGS__);              \
+        case 10: return FN<10, 4, 4>(__VA_ARGS__);            \
+        case 11: return FN<11, 4, 2>(__VA_ARGS__);            \
+        case 12: return FN<12, 4, 1>(__VA_ARGS__);            \
+        case 13: return FN<13, 4, 1>(__VA_ARGS__);            \
+        case 14: return FN<14, 4, 1>(__VA_ARGS__);            \
+        default: return FHE_ERR_UNSUPPORTED;                  \
+    }
+
+int dispatch_fwd(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) {
+    NTT_DISPATCH(launch_fwd, log_n, c, a, batch, st)
+}
+int dispatch_inv(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) {
+    NTT_DISPATCH(launch_inv, log_n, c, a, batch, st)
+}
+
+// host-memory convenience path: stage through a temporary device buffer
+template <typename F>
+int with_staging(const fhe_ctx *ctx, uint64_t *a, size_t count, hipStream_t st, F &&body) {
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc(&d, count * sizeof(u64)));
+    int rc = FHE_OK;
+    if (hipMemcpyAsync(d, a, count * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = body(d);
+    if (rc == FHE_OK && hipMemcpyAsync(a, d, count * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess)
+        rc = FHE_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(d);
+    (void)ctx;
+    return rc;
+}
+}  // namespace
+
+namespace fhe {
+
+int ctx_build_host(uint64_t q, fhe_ctx *c) {
+    if (q < 3) return FHE_ERR_INVALID;
+    if (!is_prime_u64(q)) return FHE_ERR_NOT_PRIME;
+    if (q >> 62) return FHE_ERR_UNSUPPORTED;  // lazy [0, 4q) arithmetic needs q < 2^62
+    c->q = q;
+    c->s = __builtin_ctzll(q - 1);
+    c->g = smallest_nonresidue(q);
+    c->omega = powmod(c->g, (q - 1) >> c->s, q);
+    // the reference table has 2^(s-1) entries, entry j = omega^bitrev_{s-1}(j).  Bit-reversed tables are
+    // prefix-nested, so the first 2^k entries equal psi^bitrev_k(j) with psi = omega^(2^(s-1-k)).
+    c->log_cap = c->s - 1 < MAX_LOG_N ? c->s - 1 : MAX_LOG_N;
+    const size_t cap = size_t(1) << c->log_cap;
+    const u64 psi = powmod(c->omega, u64(1) << (c->s - 1 - c->log_cap), q);
+    const u64 psi_inv = invmod(psi, q);
+    std::vector<uint64_t> pw(cap), pwi(cap);
+    uint64_t x = 1, y = 1;
+    for (size_t i = 0; i < cap; ++i) {
+        pw[i] = x; pwi[i] = y;
+        x = mulmod(x, psi, q); y = mulmod(y, psi_inv, q);
+    }
+    c->tw.resize(cap); c->twi.resize(cap);
+    for (size_t j = 0; j < cap; ++j) {
+        size_t r = bitrev((unsigned)j, c->log_cap);
+        c->tw[j] = pw[r]; c->twi[j] = pwi[r];
+    }
+    for (int k = 0; k < 32; ++k) {
+        uint64_t n = (uint64_t(1) << k) % q;
+        c->ninv[k] = n ? invmod(n, q) : 0;
+        c->ninv_s[k] = shoup(c->ninv[k], q);
+    }
+    int nbits = 64 - __builtin_clzll(q);
+    c->barrett.q = q;
+    c->barrett.mu = (u64)((((u128)1) << (2 * nbits)) / q);
+    c->barrett.sh1 = nbits - 1;
+    c->barrett.sh2 = nbits + 1;
+    return FHE_OK;
+}
+
+}  // namespace fhe
+
+extern "C" {
+
+const char *fhe_version(void) { return "learn-fhe_amd 0.1 (gfx950)"; }
+int fhe_last_hip_error(void) { return g_last_hip; }
+
+int fhe_is_prime(uint64_t q) { return fhe::is_prime_u64(q) ? 1 : 0; }
+
+int fhe_two_adic_primes(int bits, int log_n, int count, uint64_t *out) {
+    if (!out || bits <= log_n || bits > 63 || log_n < 0 || count < 0) return 0;
+    uint64_t lo = 1ull << (bits - log_n - 1), hi = 1ull << (bits - log_n);
+    int found = 0;
+    for (uint64_t k = hi - 1; k >= lo && found < count; --k) {
+        uint64_t c = (k << log_n) + 1;
+        if (fhe::is_prime_u64(c)) out[found++] = c;
+    }
+    return found;
+}
+
+int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    fhe_ctx *c = new (std::nothrow) fhe_ctx();
+    if (!c) return FHE_ERR_INVALID;
+    int rc = fhe::ctx_build_host(q, c);
+    if (rc != FHE_OK) { delete c; return rc; }
+    c->device = device;
+    if (device >= 0) {
+        DeviceGuard guard(device);
+        if (!guard.ok) { delete c; g_last_hip = (int)hipErrorInvalidDevice; return FHE_ERR_HIP; }
+        const size_t cap = c->tw.size();
+        std::vector<fhe::TwPair> pf(cap), pi(cap);
+        for (size_t j = 0; j < cap; ++j) {
+            pf[j] = {c->tw[j], fhe::shoup(c->tw[j], q)};
+            pi[j] = {c->twi[j], fhe::shoup(c->twi[j], q)};
+        }
+        hipError_t e = hipMalloc(&c->d_tw, cap * sizeof(fhe::TwPair));
+        if (e == hipSuccess) e = hipMalloc(&c->d_twi, cap * sizeof(fhe::TwPair));
+        if (e == hipSuccess) e = hipMemcpy(c->d_tw, pf.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_twi, pi.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            fhe_ctx_destroy(c);
+            return FHE_ERR_HIP;
+        }
+    }
+    *out = c;
+    return FHE_OK;
+}
+
+void fhe_ctx_destroy(fhe_ctx *c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        DeviceGuard guard(c->device);
+        if (c->d_tw) (void)hipFree(c->d_tw);
+        if (c->d_twi) (void)hipFree(c->d_twi);
+    }
+    delete c;
+}
+
+int fhe_ctx_info(const fhe_ctx *c, uint64_t *q, int *s, uint64_t *g, uint64_t *omega) {
+    if (!c) return FHE_ERR_INVALID;
+    if (q) *q = c->q;
+    if (s) *s = c->s;
+    if (g) *g = c->g;
+    if (omega) *omega = c->omega;
+    return FHE_OK;
+}
+
+int fhe_ctx_twiddles(const fhe_ctx *c, int inverse, uint64_t *out, size_t count) {
+    if (!c || !out) return FHE_ERR_INVALID;
+    const auto &t = inverse ? c->twi : c->tw;
+    if (count > t.size()) return FHE_ERR_UNSUPPORTED;
+    std::memcpy(out, t.data(), count * sizeof(uint64_t));
+    return FHE_OK;
+}
+
+int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    int rc = check_transform(ctx, a, n);
+    if (rc != FHE_OK) return rc;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n == 1 || batch == 0) return FHE_OK;
+    if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int log_n = ilog2(n);
+    if (mem == FHE_MEM_DEVICE) return dispatch_fwd(ctx, (u64 *)a, log_n, batch, st);
+    return with_staging(ctx, a, n * batch, st, [&](u64 *d) { return dispatch_fwd(ctx, d, log_n, batch, st); });
+}
+
+int fhe_ntt_inv(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    int rc = check_transform(ctx, a, n);
+    if (rc != FHE_OK) return rc;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n == 1 || batch == 0) return FHE_OK;
+    if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int log_n = ilog2(n);
+    if (mem == FHE_MEM_DEVICE) return dispatch_inv(ctx, (u64 *)a, log_n, batch, st);
+    return with_staging(ctx, a, n * batch, st, [&](u64 *d) { return dispatch_inv(ctx, d, log_n, batch, st); });
+}
+
+int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t len, fhe_mem mem, void *stream) {
+    if (!ctx || !a || !b) return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (len == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    auto run = [&](u64 *da, const u64 *db) -> int {
+        size_t blocks = (len + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(fhe::pointwise_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, da, db, len, ctx->barrett);
+        HIP_TRY(hipGetLastError());
+        return FHE_OK;
+    };
+    if (mem == FHE_MEM_DEVICE) return run((u64 *)a, (const u64 *)b);
+    u64 *db = nullptr;
+    HIP_TRY(hipMalloc(&db, len * sizeof(u64)));
+    int rc = hipMemcpyAsync(db, b, len * sizeof(u64), hipMemcpyHostToDevice, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = with_staging(ctx, a, len, st, [&](u64 *da) { return run(da, db); });
+    (void)hipFree(db);
+    return rc;
+}
+
+int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
+                void *stream) {
+    int rc = check_transform(ctx, a, n);
+    if (rc != FHE_OK) return rc;
+    if (!b) return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch == 0) return FHE_OK;
+    if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t count = n * batch;
+    const int log_n = ilog2(n);
+    // b is const: transform a scratch copy (the reference allocates one too, fft/zq.rs:21-25)
+    u64 *tb = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&tb, count * sizeof(u64), st));
+    auto run = [&](u64 *da) -> int {
+        int r = FHE_OK;
+        if (n > 1) r = dispatch_fwd(ctx, da, log_n, batch, st);
+        if (r == FHE_OK && n > 1) r = dispatch_fwd(ctx, tb, log_n, batch, st);
+        if (r == FHE_OK) {
+            size_t blocks = (count + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(fhe::pointwise_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, da, (const u64 *)tb,
+                               count, ctx->barrett);
+            if (hipGetLastError() != hipSuccess) r = FHE_ERR_HIP;
+        }
+        if (r == FHE_OK && n > 1) r = dispatch_inv(ctx, da, log_n, batch, st);
+        return r;
+    };
+    hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) {
+        if (mem == FHE_MEM_DEVICE) rc = run((u64 *)a);
+        else rc = with_staging(ctx, a, count, st, run);
+    }
+    (void)hipFreeAsync(tb, st);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""No-GPU checks of the product library: it loads, exports every symbol include/*.h declares, and its
+host-side set-up logic (primes, generator, omega, twiddle tables, status codes) matches the oracle and the
+golden vectors.  No compute entry point is exercised here (they need a GPU and have no CPU fallback)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def declared_symbols():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names += re.findall(r"\b(fhe_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(fhe):
+    lib = fhe.lib()
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert b"gfx950" in lib.fhe_version()
+
+
+def test_host_setup_matches_golden(fhe):
+    g = load_golden("moduli.json")
+    for m in g["moduli"]:
+        ctx = fhe.NttContext(m["q"], device=-1)
+        info = ctx.info()
+        assert (info["q"], info["s"], info["g"], info["omega"]) == (m["q"], m["s"], m["g"], m["omega"])
+        assert [int(x) for x in ctx.twiddles(16)] == m["tw"]
+        assert [int(x) for x in ctx.twiddles(16, inverse=True)] == m["twi"]
+    out = (C.c_uint64 * 16)()
+    assert fhe.lib().fhe_two_adic_primes(60, 16, 16, out) == 16
+    assert list(out) == g["cfg4_qs"] + g["cfg4_ps"]
+
+
+def test_twiddle_table_matches_oracle_full(fhe, cref):
+    q = 1073707009  # s = 11: the whole 2^10-entry table
+    ctx = fhe.NttContext(q, device=-1)
+    s, g, w, tw, twi = cref.twiddle_info(q, 1 << 10)
+    assert np.array_equal(ctx.twiddles(1 << 10), tw)
+    assert np.array_equal(ctx.twiddles(1 << 10, inverse=True), twi)
+    # a prime whose 2-adicity exceeds the cap still serves the reference's prefix (tables are prefix-nested)
+    q = 1152921504606584833  # first cfg4 prime
+    ctx = fhe.NttContext(q, device=-1)
+    s, g, w, tw, twi = cref.twiddle_info(q, 4096)
+    assert ctx.info()["s"] == s
+    assert np.array_equal(ctx.twiddles(4096), tw) and np.array_equal(ctx.twiddles(4096, inverse=True), twi)
+
+
+def test_status_codes(fhe):
+    lib = fhe.lib()
+    h = C.c_void_p()
+    assert lib.fhe_ctx_create(C.c_uint64(1 << 16), -1, C.byref(h)) == 2  # FHE_ERR_NOT_PRIME (fft/zq.rs:44)
+    assert lib.fhe_ctx_create(C.c_uint64(15), -1, C.byref(h)) == 2
+    assert lib.fhe_ctx_create(C.c_uint64((1 << 63) - 25), -1, C.byref(h)) in (2, 6)  # >= 2^62: unsupported
+    assert lib.fhe_is_prime(C.c_uint64(18014398509404161)) == 1
+    assert lib.fhe_is_prime(C.c_uint64(18014398509404163)) == 0
+    ctx = fhe.NttContext(1073707009, device=-1)
+    a = np.arange(8, dtype=np.uint64)
+    with pytest.raises(fhe.FheError) as e:
+        ctx.ntt_(a, 8)
+    assert e.value.code == 7  # FHE_ERR_NO_DEVICE: host-only context, no CPU fallback
+    rc = lib.fhe_ntt_fwd(ctx.handle, a.ctypes.data_as(C.c_void_p), 6, 1, 0, None)
+    assert rc == 1  # not a power of two (ring.rs:62)
+    big = np.zeros(2048, dtype=np.uint64)
+    rc = lib.fhe_ntt_fwd(ctx.handle, big.ctypes.data_as(C.c_void_p), 2048, 1, 0, None)
+    assert rc == 3  # n > 2^(s-1): no 2n-th root (fft.rs:45)

@@ -1,0 +1,152 @@
+"""GPU parity tests of the transform path, through the C ABI, against the oracle (oracle/cref.py) on
+identical seeded u64 inputs: bit-exact.  Full-size cfg2 (N = 2^14, batch 4096) is covered by
+size-independent properties."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_u64(seed, q, count):
+    """uniform in [0, q): numpy PCG64, seeded"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, q, size=count, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_golden_vectors(fhe, torch_cuda):
+    g = load_golden("ntt.json")
+    for v in g["ntt"]:
+        ctx = fhe.NttContext(v["q"])
+        a = np.array(v["a"], dtype=np.uint64)
+        d = to_dev(torch_cuda, a)
+        ctx.ntt_(d, v["n"])
+        assert to_host(d).tolist() == v["ntt"]
+        ctx.intt_(d, v["n"])
+        assert to_host(d).tolist() == v["a"]
+        h = a.copy()  # host-memory entry path
+        ctx.ntt_(h, v["n"])
+        assert h.tolist() == v["ntt"]
+    for v in g["mul"]:
+        ctx = fhe.NttContext(v["q"])
+        a, b = to_dev(torch_cuda, np.array(v["a"], dtype=np.uint64)), to_dev(torch_cuda, np.array(v["b"], dtype=np.uint64))
+        ctx.mul_(a, b, v["n"])
+        assert to_host(a).tolist() == v["c"]
+        assert to_host(b).tolist() == v["b"]  # rhs untouched
+    z = np.load(os.path.join(GOLDEN, "ntt_2p14.npz"))
+    ctx = fhe.NttContext(int(z["q"]))
+    d = to_dev(torch_cuda, z["a"])
+    ctx.ntt_(d, 1 << 14)
+    assert np.array_equal(to_host(d), z["ntt"])
+    ctx.intt_(d, 1 << 14)
+    assert np.array_equal(to_host(d), z["a"])
+
+
+@pytest.mark.parametrize("log_n", range(0, 15))
+def test_forward_inverse_vs_oracle(fhe, cref, torch_cuda, log_n):
+    """every supported size, three moduli widths, ragged batch (not a multiple of the polynomials per workgroup)"""
+    n = 1 << log_n
+    cases = [(45, 3), (30, 2), (60, 2)] if log_n <= 12 else [(60, 2), (54, 1)]
+    for bits, count in cases:
+        if bits <= log_n + 1:
+            continue
+        for q in cref.two_adic_primes(bits, log_n + 1, count):
+            batch = 67 if log_n <= 10 else 5
+            a = rand_u64(1000 * log_n + bits, q, n * batch)
+            a[:min(4, n)] = [0, q - 1, 1, q >> 1][:min(4, n)]
+            ctx = fhe.NttContext(q)
+            d = to_dev(torch_cuda, a)
+            ctx.ntt_(d, n)
+            exp = cref.ntt_fwd(q, a, n, threads=8)
+            assert np.array_equal(to_host(d), exp), (log_n, q)
+            ctx.intt_(d, n)
+            assert np.array_equal(to_host(d), a), (log_n, q)
+            # inverse alone on oracle-produced evaluations
+            d2 = to_dev(torch_cuda, exp)
+            ctx.intt_(d2, n)
+            assert np.array_equal(to_host(d2), a)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 3, 6, 9, 10])
+def test_ring_product_vs_schoolbook(fhe, cref, torch_cuda, log_n):
+    """util/src/ring.rs:443-452: a * b == nega_cyclic_schoolbook_mul(a, b)"""
+    n = 1 << log_n
+    for q in cref.two_adic_primes(45, log_n + 1, 3):
+        a, b = rand_u64(7 + log_n, q, n), rand_u64(77 + log_n, q, n)
+        ctx = fhe.NttContext(q)
+        da, db = to_dev(torch_cuda, a), to_dev(torch_cuda, b)
+        ctx.mul_(da, db, n)
+        assert np.array_equal(to_host(da), cref.schoolbook_mul(q, a, b))
+
+
+def test_pointwise_mul(fhe, cref, torch_cuda):
+    for q in (1152921504606748673, 1073707009, 18014398509404161, 97, 3):
+        a, b = rand_u64(1, q, 5000), rand_u64(2, q, 5000)
+        a[:3] = [0, q - 1, q - 1]
+        b[:3] = [q - 1, q - 1, 1]
+        ctx = fhe.NttContext(q)
+        da, db = to_dev(torch_cuda, a), to_dev(torch_cuda, b)
+        ctx.pointwise_mul_(da, db)
+        assert np.array_equal(to_host(da), cref.pointwise_mul(q, a, b))
+
+
+def test_cfg2_full_size_properties(fhe, cref, torch_cuda):
+    """BASELINE config 2: N = 2^14, q = 1152921504606748673, batch 4096 (512 MiB), device resident.
+    round trip == identity; forward == oracle on a 64-polynomial sample; linearity; checksum of evaluations
+    (sum_k NTT(a)[k] = N * a_0 ... not used: bit-reversal keeps sums) -> sum of all evaluations == N * a[0]."""
+    torch = torch_cuda
+    q, n, batch = 1152921504606748673, 1 << 14, 4096
+    ctx = fhe.NttContext(q)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2)
+    a = torch.randint(0, q, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+    ref = a.clone()
+    ctx.ntt_(a, n)
+    sample = list(range(0, batch, 64))
+    exp = cref.ntt_fwd(q, to_host(ref[sample]).reshape(-1), n, threads=8)
+    assert np.array_equal(to_host(a[sample]).reshape(-1), exp)
+    # sum over all evaluation points of a(x) = N * a_0 (roots of X^N + 1 sum to zero in every power 1..N-1)
+    ev = to_host(a[:8])
+    for r in range(8):
+        s = sum(int(v) for v in ev[r]) % q
+        assert s == (n * int(to_host(ref[r])[0])) % q
+    ctx.intt_(a, n)
+    assert torch.equal(a, ref)
+    # linearity on a slice: NTT(x + y) == NTT(x) + NTT(y) mod q
+    x, y = ref[:16].clone(), ref[16:32].clone()
+    xy = torch.where(x + y >= q, x + y - q, x + y)
+    ctx.ntt_(xy, n); ctx.ntt_(x, n); ctx.ntt_(y, n)
+    s = torch.where(x + y >= q, x + y - q, x + y)
+    assert torch.equal(xy, s)
+
+
+def test_error_behaviour_on_device(fhe, torch_cuda):
+    ctx = fhe.NttContext(1073707009)  # s = 11 -> n <= 1024
+    d = torch_cuda.zeros(2048, dtype=torch_cuda.int64, device="cuda")
+    with pytest.raises(fhe.FheError) as e:
+        ctx.ntt_(d, 2048)
+    assert e.value.code == 3
+    with pytest.raises(fhe.FheError) as e:
+        ctx.ntt_(d[:24].contiguous(), 24)
+    assert e.value.code == 1
+    empty = torch_cuda.zeros(0, dtype=torch_cuda.int64, device="cuda")
+    ctx.ntt_(empty, 8)  # empty batch is a no-op
