@@ -33,7 +33,7 @@ def cpu_baseline(sample_per_thread=48):
     import numpy as np
     from oracle import cref
     n = 1 << LOG_N
-    threads = max(1, min(os.cpu_count() or 1, cref.num_threads()))
+    threads = max(1, min(os.cpu_count() or 1, cref.num_threads(), 16))  # a 1-GPU box's CPU share is 16 cores
     rng = np.random.Generator(np.random.PCG64(2))
     # single thread (the reference's execution model)
     a1 = rng.integers(0, Q, size=n * 16, dtype=np.uint64)

@@ -47,6 +47,13 @@ def lib():
             raise FileNotFoundError(
                 "%s not found: build it with `make -C learn-fhe_amd/csrc` (or __graft_entry__.build()); "
                 "there is no CPU fallback" % _SO)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the
+        # whole process.  When torch is part of the process (tests, bench: it owns the HBM buffers and the
+        # stream we are handed) it must be loaded first so that both sides share ONE runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_SO)
         L.fhe_version.restype = C.c_char_p
         L.fhe_is_prime.argtypes = [C.c_uint64]

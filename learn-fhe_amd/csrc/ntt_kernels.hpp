@@ -34,6 +34,15 @@ struct NttCfg {
 
 __device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }
 
+// Developer-lab ablation hooks (tools/ntt_lab.hip); never defined in the product build.
+#ifdef FHE_ABLATE_NO_GLOBAL
+__device__ __forceinline__ u64 gload(const u64 *p, int i) { return (u64)i * 0x9E3779B97F4A7C15ull >> 4; }
+__device__ __forceinline__ void gstore(u64 *p, int i, u64 v) { if (v == 0xdeadbeefcafef00dull) p[i] = v; }
+#else
+__device__ __forceinline__ u64 gload(const u64 *p, int i) { return p[i]; }
+__device__ __forceinline__ void gstore(u64 *p, int i, u64 v) { p[i] = v; }
+#endif
+
 template <int I, int END, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < END) {
@@ -107,7 +116,7 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
         for (int r = 0; r < (1 << R); ++r) {
             const int i = pass_index<LOG_N, L0, R>(grp, r);
-            if constexpr (first) x[gg * (1 << R) + r] = active ? g[i] : 0;
+            if constexpr (first) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
             else x[gg * (1 << R) + r] = lds[lds_phys(i)];
         }
     }
@@ -115,7 +124,9 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
     static_for<0, G>([&](auto gg_c) {
         constexpr int gg = decltype(gg_c)::value;
         const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
+#ifndef FHE_ABLATE_NO_COMPUTE
         fwd_pass_regs<L0, R, gg * (1 << R), E>(x, top, tw, q, q2);
+#endif
     });
     // store
     if constexpr (last && C::P == 1) {
@@ -123,7 +134,7 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r)
-                if (active) g[pass_index<LOG_N, L0, R>(t + C::T * gg, r)] = canon4(x[gg * (1 << R) + r], q, q2);
+                if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), canon4(x[gg * (1 << R) + r], q, q2));
     } else {
 #pragma unroll
         for (int gg = 0; gg < G; ++gg)
@@ -157,7 +168,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 #pragma unroll
             for (int k = 0; k < C::E; ++k) {
                 const int i = t + C::T * k;
-                g[i] = lds[lds_phys(i)];
+                gstore(g, i, lds[lds_phys(i)]);
             }
         }
     }
@@ -180,14 +191,16 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
         for (int r = 0; r < (1 << R); ++r) {
             const int i = pass_index<LOG_N, L0, R>(grp, r);
-            if constexpr (C::P == 1) x[gg * (1 << R) + r] = active ? g[i] : 0;
+            if constexpr (C::P == 1) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
             else x[gg * (1 << R) + r] = lds[lds_phys(i)];
         }
     }
     static_for<0, G>([&](auto gg_c) {
         constexpr int gg = decltype(gg_c)::value;
         const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
+#ifndef FHE_ABLATE_NO_COMPUTE
         inv_pass_regs<L0, R, gg * (1 << R), E>(x, top, twi, q, q2);
+#endif
     });
     if constexpr (final_pass) {
         // * n^-1 (util/src/ring/fft.rs:76), canonicalise, store: consecutive lanes -> consecutive addresses
@@ -196,7 +209,7 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
                 const u64 v = csub(mul_shoup_lazy(x[gg * (1 << R) + r], ninv, ninv_s, q), q);
-                if (active) g[pass_index<LOG_N, L0, R>(t + C::T * gg, r)] = v;
+                if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), v);
             }
     } else {
 #pragma unroll
@@ -225,7 +238,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
 #pragma unroll
         for (int k = 0; k < C::E; ++k) {
             const int i = t + C::T * k;
-            lds[lds_phys(i)] = active ? g[i] : 0;
+            lds[lds_phys(i)] = active ? gload(g, i) : 0;
         }
         __syncthreads();
     }

@@ -26,8 +26,8 @@ inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline int ilog2(size_t n) { return 63 - __builtin_clzll((unsigned long long)n); }
 
 // validates (ctx, n) the way the reference would panic
-int check_transform(const fhe_ctx *ctx, const void *a, size_t n) {
-    if (!ctx || !a || !is_pow2(n)) return FHE_ERR_INVALID;
+int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
+    if (!ctx || !is_pow2(n) || (!a && batch)) return FHE_ERR_INVALID;
     if (n == 1) return FHE_OK;
     int log_n = ilog2(n);
     if (log_n > ctx->s - 1) return FHE_ERR_NO_ROOT;
@@ -39,7 +39,11 @@ struct DeviceGuard {
     int prev = -1;
     bool ok = true;
     explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(dev) != hipSuccess) ok = false;
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) prev = -1;
+        if (prev != dev) e = hipSetDevice(dev);
+        if (e != hipSuccess) { ok = false; g_last_hip = (int)e; }
+        if (prev == dev) prev = -1;  // nothing to restore
     }
     ~DeviceGuard() {
         if (prev >= 0) (void)hipSetDevice(prev);
@@ -186,7 +190,7 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
     c->device = device;
     if (device >= 0) {
         DeviceGuard guard(device);
-        if (!guard.ok) { delete c; g_last_hip = (int)hipErrorInvalidDevice; return FHE_ERR_HIP; }
+        if (!guard.ok) { delete c; return FHE_ERR_HIP; }
         const size_t cap = c->tw.size();
         std::vector<fhe::TwPair> pf(cap), pi(cap);
         for (size_t j = 0; j < cap; ++j) {
@@ -235,7 +239,7 @@ int fhe_ctx_twiddles(const fhe_ctx *c, int inverse, uint64_t *out, size_t count)
 }
 
 int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
-    int rc = check_transform(ctx, a, n);
+    int rc = check_transform(ctx, a, n, batch);
     if (rc != FHE_OK) return rc;
     if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
     if (n == 1 || batch == 0) return FHE_OK;
@@ -249,7 +253,7 @@ int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem
 }
 
 int fhe_ntt_inv(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
-    int rc = check_transform(ctx, a, n);
+    int rc = check_transform(ctx, a, n, batch);
     if (rc != FHE_OK) return rc;
     if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
     if (n == 1 || batch == 0) return FHE_OK;
@@ -287,9 +291,9 @@ int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t
 
 int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
                 void *stream) {
-    int rc = check_transform(ctx, a, n);
+    int rc = check_transform(ctx, a, n, batch);
     if (rc != FHE_OK) return rc;
-    if (!b) return FHE_ERR_INVALID;
+    if (!b && batch) return FHE_ERR_INVALID;
     if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
     if (batch == 0) return FHE_OK;
     if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
