@@ -74,6 +74,58 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
 /* util/src/ring.rs:266-270 evaluation-domain `MulAssign`: a[i] <- a[i] * b[i] mod q, len elements. */
 int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t len, fhe_mem mem, void *stream);
 
+/* ---- gadget decomposition, automorphism, monomial (any modulus q < 2^62, on the current HIP device) ---- */
+/* util/src/misc/decompose.rs:42-46 `Base2Decomposor::<Zq>::new(q, log_b, d).decompose(poly)`:
+ * in [polys][n] -> out [polys][d][n], digit j of coefficient i of polynomial p at out[(p*d + j)*n + i],
+ * least-significant digit first, digits in [-B/2, B/2] mod q exactly as decompose.rs:91-112 produces them. */
+int fhe_decompose(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem,
+                  void *stream);
+/* util/src/avec.rs:34-50 `automorphism(t)`: X -> X^t, t taken mod 2n; out must not alias in. */
+int fhe_automorphism(uint64_t q, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                     void *stream);
+/* util/src/ring.rs:299-313 `Rq *= X^k`, k taken mod 2n; out must not alias in. */
+int fhe_monomial_mul(uint64_t q, int64_t k, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                     void *stream);
+
+/* ---- prepared gadget keys (device resident, evaluation domain) ---------------------------------------- */
+typedef struct fhe_key fhe_key;
+/* `count` RGSW ciphertexts (scheme/fhew/src/rgsw.rs:37-47, 84-105): rows_a / rows_b = the a / b polynomials of the
+ * 2d RLWE rows of each, [count][2d][n], coefficient domain.  n = 128 .. 2048. */
+int fhe_rgsw_prepare(const fhe_ctx *ctx, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n,
+                     size_t count, fhe_mem mem, fhe_key **out);
+/* `count` RLWE key-switching / automorphism keys (scheme/fhew/src/rlwe.rs:43-66, 109-132): [count][d][n]. */
+int fhe_ksk_prepare(const fhe_ctx *ctx, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n,
+                    size_t count, fhe_mem mem, fhe_key **out);
+void fhe_key_destroy(fhe_key *key);
+
+/* scheme/fhew/src/rgsw.rs:116-128 `Rgsw::external_product(param, rgsw[index], ct)` for `batch` RLWE ciphertexts
+ * (ct_a, ct_b: [batch][n], coefficient domain, in place). */
+int fhe_external_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, uint64_t *ct_a, uint64_t *ct_b,
+                         size_t batch, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rlwe.rs:177-186 `Rlwe::key_switch(param, ksk[index], ct)`. */
+int fhe_rlwe_key_switch(const fhe_ctx *ctx, const fhe_key *ksk, size_t index, uint64_t *ct_a, uint64_t *ct_b,
+                        size_t batch, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism(param, ak[index] (exponent t), ct)`. */
+int fhe_rlwe_automorphism(const fhe_ctx *ctx, const fhe_key *ak, size_t index, int64_t t, uint64_t *ct_a,
+                          uint64_t *ct_b, size_t batch, fhe_mem mem, void *stream);
+
+/* ---- LMKCDEY blind rotation --------------------------------------------------------------------------- */
+typedef struct fhe_bootstrap_key fhe_bootstrap_key;
+/* scheme/fhew/src/bootstrapping.rs:93-113 `BootstrappingKey{brk, ak}` (the LWE ksk belongs to the "next" row):
+ * brk = n_lwe prepared RGSW ciphertexts, ak = w+1 prepared automorphism keys with exponents ak_t[0..w]
+ * (= [-g, g, g^2, .., g^w] mod 2n, bootstrapping.rs:86-89).  The handles must outlive the bootstrap key. */
+int fhe_bootstrap_key_create(const fhe_ctx *ctx, const fhe_key *brk, const fhe_key *ak, const int64_t *ak_t, int w,
+                             fhe_bootstrap_key **out);
+void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk);
+/* scheme/fhew/src/bootstrapping.rs:158-209 `blind_rotate(param, brk, ak, f, LweCiphertext(a, b))` for a batch:
+ * lwe_a [batch][n_lwe] and lwe_b [batch] are taken mod 2n (after mod_switch_odd); f = LUT polynomial(s),
+ * f_stride = 0 (one f) or n (one per ciphertext); out_a/out_b [batch][n] = the rotated accumulator.
+ * ops_out/nops_out (host pointers, may be NULL): the walk of blind_rotate_core per ciphertext,
+ * [batch][n_lwe + n + 2] entries, bit 31 set = automorphism ak[idx], clear = external product brk[idx]. */
+int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const uint64_t *lwe_b, const uint64_t *f,
+                     size_t f_stride, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream,
+                     uint32_t *ops_out, uint32_t *nops_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,23 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.fhe_ntt_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.fhe_pointwise_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        i64p = C.POINTER(C.c_int64)
+        u32p = C.POINTER(C.c_uint32)
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+        L.fhe_decompose.argtypes = [C.c_uint64, ci, ci, vp, sz, sz, vp, ci, vp]
+        L.fhe_automorphism.argtypes = [C.c_uint64, C.c_int64, vp, vp, sz, sz, ci, vp]
+        L.fhe_monomial_mul.argtypes = [C.c_uint64, C.c_int64, vp, vp, sz, sz, ci, vp]
+        for name in ("fhe_rgsw_prepare", "fhe_ksk_prepare"):
+            getattr(L, name).argtypes = [vp, ci, ci, vp, vp, sz, sz, ci, C.POINTER(vp)]
+        L.fhe_key_destroy.argtypes = [vp]
+        L.fhe_key_destroy.restype = None
+        for name in ("fhe_external_product", "fhe_rlwe_key_switch"):
+            getattr(L, name).argtypes = [vp, vp, sz, vp, vp, sz, ci, vp]
+        L.fhe_rlwe_automorphism.argtypes = [vp, vp, sz, C.c_int64, vp, vp, sz, ci, vp]
+        L.fhe_bootstrap_key_create.argtypes = [vp, vp, vp, i64p, ci, C.POINTER(vp)]
+        L.fhe_bootstrap_key_destroy.argtypes = [vp]
+        L.fhe_bootstrap_key_destroy.restype = None
+        L.fhe_blind_rotate.argtypes = [vp, vp, vp, vp, sz, vp, vp, sz, ci, vp, u32p, u32p]
         _lib = L
     return _lib
 

@@ -1,0 +1,384 @@
+// extern "C" entry points for SURVEY.md section 8(a) rows a8-a13: decomposition, automorphism, monomial
+// multiply, prepared gadget keys, external product, RLWE key switch, LMKCDEY blind rotation.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "api_common.hpp"
+#include "ctx.hpp"
+#include "fhew_kernels.hpp"
+
+// defined in ring_api.hip
+namespace fhe {
+int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st);
+}
+
+struct fhe_key {
+    const fhe_ctx *ctx = nullptr;
+    int log_n = 0;
+    int log_b = 0, d = 0;
+    int rows_per_ct = 0;  // 2d (RGSW) or d (key-switching key)
+    size_t count = 0;
+    u64 *d_rows = nullptr;  // [count][rows_per_ct][2][N], evaluation domain, key_perm layout
+    fhe::DecompParams P{};
+};
+
+struct fhe_bootstrap_key {
+    const fhe_ctx *ctx = nullptr;
+    const fhe_key *brk = nullptr, *ak = nullptr;
+    int w = 0;
+    unsigned *d_ak_t = nullptr;  // [w + 1] exponents mod 2N
+    unsigned *d_dlog = nullptr;  // [2N]
+};
+
+namespace {
+
+int make_decomp(uint64_t q, int log_b, int d, fhe::DecompParams *P) {
+    if (q < 2 || log_b < 1 || log_b > 62 || d < 1 || d > 64) return FHE_ERR_INVALID;
+    if ((q >> 62) || (1ull << log_b) >= q) return FHE_ERR_UNSUPPORTED;
+    const int log_q = q <= 1 ? 0 : 64 - __builtin_clzll(q - 1);  // q.next_power_of_two().ilog2()
+    const int rb = log_q - log_b * d > 0 ? log_q - log_b * d : 0;
+    P->q = q;
+    P->rnd = ((1ull << rb) >> 1) % q;
+    P->neg_b = q - (1ull << log_b);
+    P->mask = (1ull << log_b) - 1;
+    P->b_by_2 = 1ull << (log_b - 1);
+    P->log_b = log_b;
+    P->d = d;
+    P->rb = rb;
+    return FHE_OK;
+}
+
+inline unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+fhe::RingConsts ring_consts(const fhe_ctx *c, int log_n) {
+    fhe::RingConsts K;
+    K.q = c->q;
+    K.q2 = 2 * c->q;
+    K.tw = c->d_tw;
+    K.twi = c->d_twi;
+    K.ninv = c->ninv[log_n];
+    K.ninv_s = c->ninv_s[log_n];
+    K.B = c->barrett;
+    return K;
+}
+
+#define FHEW_DISPATCH(log_n, ...)                                          \
+    switch (log_n) {                                                       \
+        case 7: { constexpr int LN = 7; __VA_ARGS__; break; }              \
+        case 8: { constexpr int LN = 8; __VA_ARGS__; break; }              \
+        case 9: { constexpr int LN = 9; __VA_ARGS__; break; }              \
+        case 10: { constexpr int LN = 10; __VA_ARGS__; break; }            \
+        case 11: { constexpr int LN = 11; __VA_ARGS__; break; }            \
+        default: return FHE_ERR_UNSUPPORTED;                               \
+    }
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return FHE_OK;
+}
+
+int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uint64_t *rows_a, const uint64_t *rows_b, size_t n,
+                size_t count, fhe_mem mem, fhe_key **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!ctx || !rows_a || !rows_b || !is_pow2(n) || count == 0) return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    const int log_n = ilog2(n);
+    if (log_n > ctx->s - 1) return FHE_ERR_NO_ROOT;
+    if (log_n < 7 || log_n > 11) return FHE_ERR_UNSUPPORTED;
+    fhe::DecompParams P;
+    int rc = make_decomp(ctx->q, log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * rows_per_ct, words = rows * n;
+    hipStream_t st = nullptr;
+    u64 *ta = nullptr, *tb = nullptr, *dst = nullptr;
+    HIP_TRY(hipMalloc((void **)&ta, 2 * words * sizeof(u64)));
+    tb = ta + words;
+    hipError_t e = hipMalloc((void **)&dst, 2 * words * sizeof(u64));
+    hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (e == hipSuccess) e = hipMemcpyAsync(ta, rows_a, words * sizeof(u64), kind, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(tb, rows_b, words * sizeof(u64), kind, st);
+    rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (e != hipSuccess) g_last_hip = (int)e;
+    // rows -> evaluation domain once (what Rgsw::internal_product does per call, rgsw.rs:136-138)
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_device(ctx, ta, log_n, 2 * rows, st);
+    if (rc == FHE_OK) {
+        FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows));
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(ta);
+    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); return rc; }
+    fhe_key *k = new (std::nothrow) fhe_key();
+    if (!k) { (void)hipFree(dst); return FHE_ERR_INVALID; }
+    k->ctx = ctx; k->log_n = log_n; k->log_b = log_b; k->d = d; k->rows_per_ct = rows_per_ct; k->count = count;
+    k->d_rows = dst; k->P = P;
+    *out = k;
+    return FHE_OK;
+}
+
+fhe::FhewKey key_view(const fhe_key *k) {
+    fhe::FhewKey v;
+    v.rows = k->d_rows;
+    v.rows_per_ct = k->rows_per_ct;
+    v.P = k->P;
+    return v;
+}
+
+int check_ct_call(const fhe_ctx *ctx, const fhe_key *key, size_t index, const void *a, const void *b, size_t batch) {
+    if (!ctx || !key || ((!a || !b) && batch)) return FHE_ERR_INVALID;
+    if (key->ctx != ctx) return FHE_ERR_MODULUS;
+    if (index >= key->count) return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
+    return FHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fhe_decompose(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem,
+                  void *stream) {
+    fhe::DecompParams P;
+    int rc = make_decomp(q, log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    if ((!in || !out) && n * polys) return FHE_ERR_INVALID;
+    if (n * polys == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, n * polys, mem, true, st), mo(out, n * polys * d, mem, false, st);
+    if (mi.rc != FHE_OK || mo.rc != FHE_OK) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(grid_for(n * polys)), dim3(256), 0, st, mi.d, mo.d, n, polys, P);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_automorphism(uint64_t q, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                     void *stream) {
+    if (q < 2 || !is_pow2(n) || n > (1u << 30) || ((!in || !out) && batch) || in == out) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const int64_t two_n = 2 * (int64_t)n;
+    const unsigned tt = (unsigned)(((t % two_n) + two_n) % two_n);  // t.rem_euclid(2n), avec.rs:38
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, n * batch, mem, true, st), mo(out, n * batch, mem, true, st);  // copy_in: untouched slots keep `in` values
+    if (mi.rc != FHE_OK || mo.rc != FHE_OK) return FHE_ERR_HIP;
+    // `let mut v = self.clone()` (avec.rs:36): positions no X^(i t) lands on keep the input value (even t)
+    HIP_TRY(hipMemcpyAsync(mo.d, mi.d, n * batch * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(fhe::automorphism_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, mo.d, (unsigned)n, batch, tt, (u64)q);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_monomial_mul(uint64_t q, int64_t k, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                     void *stream) {
+    if (q < 2 || !is_pow2(n) || n > (1u << 30) || ((!in || !out) && batch) || in == out) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const int64_t two_n = 2 * (int64_t)n;
+    const unsigned kk = (unsigned)(((k % two_n) + two_n) % two_n);  // rem_euclid(2n), ring.rs:305
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, n * batch, mem, true, st), mo(out, n * batch, mem, false, st);
+    if (mi.rc != FHE_OK || mo.rc != FHE_OK) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::monomial_mul_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, mo.d, (unsigned)n, batch, kk, (u64)q);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_rgsw_prepare(const fhe_ctx *ctx, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n,
+                     size_t count, fhe_mem mem, fhe_key **out) {
+    return key_prepare(ctx, log_b, d, 2 * d, rows_a, rows_b, n, count, mem, out);
+}
+
+int fhe_ksk_prepare(const fhe_ctx *ctx, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n,
+                    size_t count, fhe_mem mem, fhe_key **out) {
+    return key_prepare(ctx, log_b, d, d, rows_a, rows_b, n, count, mem, out);
+}
+
+void fhe_key_destroy(fhe_key *k) {
+    if (!k) return;
+    if (k->ctx && k->ctx->device >= 0) {
+        DeviceGuard guard(k->ctx->device);
+        if (k->d_rows) (void)hipFree(k->d_rows);
+    }
+    delete k;
+}
+
+static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bool both, bool is_auto, int64_t t, uint64_t *ct_a,
+                        uint64_t *ct_b, size_t batch, fhe_mem mem, void *stream) {
+    int rc = check_ct_call(ctx, key, index, ct_a, ct_b, batch);
+    if (rc != FHE_OK) return rc;
+    if (key->rows_per_ct != (both ? 2 : 1) * key->d) return FHE_ERR_INVALID;  // RGSW key vs key-switching key
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << key->log_n;
+    unsigned tt = 1;
+    if (is_auto) {
+        const int64_t two_n = 2 * (int64_t)n;
+        tt = (unsigned)(((t % two_n) + two_n) % two_n);
+        if ((tt & 1) == 0) return FHE_ERR_INVALID;  // only odd t are ring automorphisms
+    }
+    Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
+    if (ma.rc != FHE_OK || mb.rc != FHE_OK) return FHE_ERR_HIP;
+    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
+    FHEW_DISPATCH(key->log_n, {
+        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;
+        rc = set_lds(fhe::gadget_product_kernel<LN>, lds);
+        if (rc != FHE_OK) return rc;
+        hipLaunchKernelGGL(fhe::gadget_product_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, ma.d, mb.d,
+                           (unsigned)batch, key_view(key), (unsigned)index, both ? 1u : 0u, tt, ring_consts(ctx, LN));
+    });
+    HIP_TRY(hipGetLastError());
+    rc = ma.sync_out(st);
+    return rc != FHE_OK ? rc : mb.sync_out(st);
+}
+
+int fhe_external_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, uint64_t *ct_a, uint64_t *ct_b, size_t batch,
+                         fhe_mem mem, void *stream) {
+    return gadget_entry(ctx, rgsw, index, true, false, 1, ct_a, ct_b, batch, mem, stream);
+}
+
+int fhe_rlwe_key_switch(const fhe_ctx *ctx, const fhe_key *ksk, size_t index, uint64_t *ct_a, uint64_t *ct_b, size_t batch,
+                        fhe_mem mem, void *stream) {
+    return gadget_entry(ctx, ksk, index, false, false, 1, ct_a, ct_b, batch, mem, stream);
+}
+
+int fhe_rlwe_automorphism(const fhe_ctx *ctx, const fhe_key *ak, size_t index, int64_t t, uint64_t *ct_a, uint64_t *ct_b,
+                          size_t batch, fhe_mem mem, void *stream) {
+    return gadget_entry(ctx, ak, index, false, true, t, ct_a, ct_b, batch, mem, stream);
+}
+
+int fhe_bootstrap_key_create(const fhe_ctx *ctx, const fhe_key *brk, const fhe_key *ak, const int64_t *ak_t, int w,
+                             fhe_bootstrap_key **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!ctx || !brk || !ak || !ak_t || w < 1) return FHE_ERR_INVALID;
+    if (brk->ctx != ctx || ak->ctx != ctx) return FHE_ERR_MODULUS;
+    if (brk->log_n != ak->log_n || ak->count != (size_t)w + 1 || brk->rows_per_ct != 2 * brk->d || ak->rows_per_ct != ak->d)
+        return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    const unsigned n = 1u << brk->log_n, q2 = 2 * n;
+    std::vector<unsigned> t(w + 1), dlog(q2, 0xffffffffu);
+    for (int i = 0; i <= w; ++i) {
+        int64_t v = ((ak_t[i] % (int64_t)q2) + q2) % q2;
+        if ((v & 1) == 0) return FHE_ERR_INVALID;
+        t[i] = (unsigned)v;
+    }
+    unsigned x = 1;  // log_g_map (bootstrapping.rs:228-231): +-5^l -> l, l < n/2
+    for (unsigned l = 0; l < n / 2; ++l) {
+        dlog[x] = (l << 1) | 0u;
+        dlog[(q2 - x) % q2] = (l << 1) | 1u;
+        x = (unsigned)((uint64_t)x * 5u % q2);
+    }
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    fhe_bootstrap_key *bk = new (std::nothrow) fhe_bootstrap_key();
+    if (!bk) return FHE_ERR_INVALID;
+    bk->ctx = ctx; bk->brk = brk; bk->ak = ak; bk->w = w;
+    hipError_t e = hipMalloc((void **)&bk->d_ak_t, t.size() * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&bk->d_dlog, dlog.size() * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemcpy(bk->d_ak_t, t.data(), t.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(bk->d_dlog, dlog.data(), dlog.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        if (bk->d_ak_t) (void)hipFree(bk->d_ak_t);
+        if (bk->d_dlog) (void)hipFree(bk->d_dlog);
+        delete bk;
+        return FHE_ERR_HIP;
+    }
+    *out = bk;
+    return FHE_OK;
+}
+
+void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk) {
+    if (!bk) return;
+    if (bk->ctx && bk->ctx->device >= 0) {
+        DeviceGuard guard(bk->ctx->device);
+        if (bk->d_ak_t) (void)hipFree(bk->d_ak_t);
+        if (bk->d_dlog) (void)hipFree(bk->d_dlog);
+    }
+    delete bk;
+}
+
+// ops_out (host, optional): [batch][max_ops] with max_ops = n_lwe + N + 2, nops_out: [batch] -- lets tests compare the walk of
+// blind_rotate_core with the oracle's.  Entry: bit 31 set -> automorphism ak[idx], else external product brk[idx].
+int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const uint64_t *lwe_b, const uint64_t *f, size_t f_stride,
+                     uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream, uint32_t *ops_out,
+                     uint32_t *nops_out) {
+    if (!bk || ((!lwe_a || !lwe_b || !f || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    const fhe_ctx *ctx = bk->ctx;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch == 0) return FHE_OK;
+    if (batch > 0x7fffffffull) return FHE_ERR_UNSUPPORTED;
+    const int log_n = bk->brk->log_n;
+    const size_t n = size_t(1) << log_n, n_lwe = bk->brk->count;
+    if (f_stride != 0 && f_stride != n) return FHE_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror ma(lwe_a, n_lwe * batch, mem, true, st), mb(lwe_b, batch, mem, true, st), mf(f, f_stride ? n * batch : n, mem, true, st);
+    Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
+    if (ma.rc | mb.rc | mf.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    const unsigned max_ops = (unsigned)(n_lwe + n + 2);
+    const size_t scratch_words = batch * (2 * n_lwe + n + 2);
+    unsigned *ws = nullptr;  // ops | nops | scratch | err
+    const size_t ws_words = batch * max_ops + batch + scratch_words + 1;
+    HIP_TRY(hipMalloc((void **)&ws, ws_words * sizeof(unsigned)));
+    unsigned *d_ops = ws, *d_nops = ws + batch * max_ops, *d_scratch = d_nops + batch;
+    int *d_err = (int *)(d_scratch + scratch_words);
+    int rc = FHE_OK;
+    auto fail = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(ws); return code; };
+    if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) return fail(FHE_ERR_HIP);
+    hipLaunchKernelGGL(fhe::blind_rotate_schedule_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ma.d, (unsigned)n_lwe,
+                       (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_scratch, d_err);
+    if (hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
+    fhe::BlindRotateParams BR;
+    BR.brk = key_view(bk->brk);
+    BR.ak = key_view(bk->ak);
+    BR.ak_t = bk->d_ak_t;
+    BR.ops = d_ops;
+    BR.nops = d_nops;
+    BR.max_ops = max_ops;
+    BR.lwe_b = mb.d;
+    BR.f = mf.d;
+    BR.f_stride = f_stride;
+    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
+    switch (log_n) {
+#define BR_CASE(LN)                                                                                                         \
+    case LN: {                                                                                                              \
+        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;                                   \
+        rc = set_lds(fhe::blind_rotate_kernel<LN>, lds);                                                                    \
+        if (rc == FHE_OK)                                                                                                   \
+            hipLaunchKernelGGL(fhe::blind_rotate_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, BR, moa.d, \
+                               mob.d, (unsigned)batch, ring_consts(ctx, LN));                                              \
+        break;                                                                                                              \
+    }
+        BR_CASE(7) BR_CASE(8) BR_CASE(9) BR_CASE(10) BR_CASE(11)
+#undef BR_CASE
+        default: return fail(FHE_ERR_UNSUPPORTED);
+    }
+    if (rc != FHE_OK || hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
+    int h_err = 0;
+    if (hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FHE_ERR_HIP);
+    if (ops_out && nops_out) {
+        if (hipMemcpyAsync(ops_out, d_ops, batch * max_ops * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(nops_out, d_nops, batch * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return fail(FHE_ERR_HIP);
+    }
+    rc = moa.sync_out(st);
+    if (rc == FHE_OK) rc = mob.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // workspace + h_err must be complete
+    (void)hipFree(ws);
+    if (rc == FHE_OK && h_err) rc = FHE_ERR_INVALID;  // an LWE coefficient outside the odd residues mod 2N (bootstrapping.rs:221)
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,373 @@
+// FHEW-side kernels: gadget decomposition, automorphism, monomial
+// multiply, and the fused RLWE x RGSW external product / RLWE key switch / LMKCDEY blind rotation.
+//
+// Fused kernels: ONE wave64 owns one RLWE ciphertext.  The accumulator (a, b) lives in registers across the
+// whole chain; every decomposed limb is transformed by a wave-private NTT (registers + a wave-private LDS
+// image, no workgroup barrier anywhere), multiplied into evaluation-domain sums against key rows that were
+// transformed once at key-preparation time, and only 2 inverse transforms per step bring the result back:
+// 2d+2 transforms per external product instead of the reference's 12d (scheme/fhew/src/rgsw.rs:116-128
+// over util/src/ring/fft/zq.rs:14-19), d+2 instead of 6d per key switch (rlwe.rs:177-186).  All sums are
+// exact mod q, so the coefficient-domain outputs are bit-identical to the reference's.
+#pragma once
+#include "ntt_kernels.hpp"
+
+namespace fhe {
+
+// ---- gadget decomposition (util/src/misc/decompose.rs:49-64, 91-112) ---------------------------
+struct DecompParams {
+    u64 q;
+    u64 rnd;      // ((1 << rounding_bits) >> 1) % q
+    u64 neg_b;    // q - 2^log_b
+    u64 mask;     // 2^log_b - 1
+    u64 b_by_2;   // 2^(log_b - 1)
+    int log_b, d, rb;
+};
+
+// rounding_shr + to_center_u64: the running two's-complement state the digits are peeled from
+__device__ __forceinline__ u64 decomp_init(u64 v, const DecompParams &P) {
+    u64 r = csub(v + P.rnd, P.q) >> P.rb;      // Zq + u64, then >> bits (decompose.rs:92-95)
+    return r < (P.q >> 1) ? r : r - P.q;       // zq.rs:83-89 (wrapping)
+}
+
+__device__ __forceinline__ u64 decomp_next(u64 &c, const DecompParams &P) {
+    const u64 limb = c & P.mask;
+    const u64 carry = (limb + (c & 1)) > P.b_by_2;
+    c = (c >> P.log_b) + carry;
+    return limb + (carry ? P.neg_b : 0);       // < q because limb < 2^log_b
+}
+
+// in: [polys][n]   out: [polys][d][n] (digit-major per polynomial, least significant first)
+__global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, DecompParams P) {
+    const size_t total = n * polys;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        u64 c = decomp_init(in[idx], P);
+        for (int j = 0; j < P.d; ++j) out[(p * P.d + j) * n + i] = decomp_next(c, P);
+    }
+}
+
+// ---- automorphism X -> X^t (util/src/avec.rs:34-50) and monomial multiply (util/src/ring.rs:299-313) ----
+__global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned t, u64 q) {
+    const size_t total = size_t(n) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned i = unsigned(idx - p * n);
+        const unsigned it = unsigned((u64(i) * t) & (2 * n - 1));
+        const u64 v = in[idx];
+        if (it < n) out[p * n + it] = v;
+        else out[p * n + it - n] = v ? q - v : 0;
+    }
+}
+
+__global__ void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned k2n, u64 q) {
+    const size_t total = size_t(n) * batch;
+    const unsigned r = k2n & (n - 1);
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned j = unsigned(idx - p * n);
+        const unsigned dst = (j + r) & (n - 1);
+        const bool neg = k2n < n ? dst < k2n : dst >= k2n - n;
+        const u64 v = in[idx];
+        out[p * n + dst] = neg ? (v ? q - v : 0) : v;
+    }
+}
+
+// ---- wave-owned ring element -------------------------------------------------------------------
+template <int LOG_N>
+struct WaveRing {
+    static constexpr int LOG_E = LOG_N - 6;
+    static constexpr int E = 1 << LOG_E;
+    static constexpr int N = 1 << LOG_N;
+    using C = NttCfg<LOG_N, LOG_E, 1>;  // T = 64: one wave
+    static constexpr int R0 = C::R0;
+    static constexpr int PN = C::PN;
+    static_assert(LOG_N >= 7 && LOG_N <= 11, "fused FHEW kernels cover N = 128 .. 2048");
+};
+
+// polynomial index held by register k of `lane` in the coefficient (first-pass) layout
+template <int LOG_N>
+__device__ __forceinline__ int coef_index(int lane, int k) {
+    using W = WaveRing<LOG_N>;
+    const int gg = k >> W::R0, r = k & ((1 << W::R0) - 1);
+    return pass_index<LOG_N, 0, W::R0>(lane + 64 * gg, r);
+}
+
+// key rows are stored so that the evaluation-layout registers (evaluation lane*E + r in x[r]) load as
+// coalesced 16-byte pairs: word offset of evaluation e = lane*E + r inside a row
+template <int LOG_N>
+__host__ __device__ __forceinline__ int key_perm(int e) {
+    constexpr int E = 1 << (LOG_N - 6);
+    const int lane = e / E, r = e % E;
+    return (r >> 1) * 128 + lane * 2 + (r & 1);
+}
+
+struct RingConsts {
+    u64 q, q2;
+    const TwPair *tw, *twi;
+    u64 ninv, ninv_s;
+    Barrett B;
+};
+
+// sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
+template <int LOG_N>
+__device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&sa)[1 << (LOG_N - 6)], u64 (&sb)[1 << (LOG_N - 6)],
+                                        const u64 *__restrict__ row, int lane, const RingConsts &K) {
+    constexpr int E = 1 << (LOG_N - 6), N = 1 << LOG_N;
+    const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
+    const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
+#pragma unroll
+    for (int r2 = 0; r2 < E / 2; ++r2) {
+        const ulonglong2 a = ka[r2 * 64 + lane], b = kb[r2 * 64 + lane];
+        const u64 x0 = canon4(x[2 * r2], K.q, K.q2), x1 = canon4(x[2 * r2 + 1], K.q, K.q2);
+        sa[2 * r2] = csub(sa[2 * r2] + mulmod_barrett(x0, a.x, K.B), K.q);
+        sa[2 * r2 + 1] = csub(sa[2 * r2 + 1] + mulmod_barrett(x1, a.y, K.B), K.q);
+        sb[2 * r2] = csub(sb[2 * r2] + mulmod_barrett(x0, b.x, K.B), K.q);
+        sb[2 * r2 + 1] = csub(sb[2 * r2 + 1] + mulmod_barrett(x1, b.y, K.B), K.q);
+    }
+}
+
+// Gadget product shared by the external product and the key switch (one transform instance each way):
+//   both = true : scheme/fhew/src/rgsw.rs:116-128   limbs = decompose(a) ++ decompose(b), rows = 2d,
+//                 (a, b) <- (sum_j rows[j].a * limb_j, sum_j rows[j].b * limb_j)
+//   both = false: scheme/fhew/src/rlwe.rs:177-186   limbs = decompose(a), rows = d,
+//                 (a, b) <- (sum_j rows[j].a * limb_j, sum_j rows[j].b * limb_j + b)
+// Each limb is transformed by the wave-private NTT and multiplied into evaluation-domain sums; two inverse
+// transforms bring the result back.  (ca, cb): coefficient layout, canonical, in and out.
+template <int LOG_N>
+__device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)], u64 (&cb)[1 << (LOG_N - 6)],
+                                                    const u64 *__restrict__ rows, const DecompParams &P, bool both, int lane,
+                                                    u64 *lds, const RingConsts &K) {
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E;
+    u64 sa[E], sb[E], st[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { sa[k] = sb[k] = 0; st[k] = decomp_init(ca[k], P); }
+    const int total = both ? 2 * P.d : P.d;
+#pragma unroll 1
+    for (int j = 0; j < total; ++j) {
+        if (both && j == P.d) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) st[k] = decomp_init(cb[k], P);
+        }
+        u64 x[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = decomp_next(st[k], P);
+        fwd_run<typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, K.tw, K.q, K.q2);
+        mac_row<LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, K);
+    }
+    // two inverse transforms through ONE instance: transform sa, swap, transform again
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        inv_run<typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, K.twi, K.q, K.q2, K.ninv, K.ninv_s);
+#pragma unroll
+        for (int k = 0; k < E; ++k) { const u64 t = sa[k]; sa[k] = sb[k]; sb[k] = t; }
+    }
+    // after two swaps sa / sb are back in place
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        ca[k] = sa[k];
+        cb[k] = both ? sb[k] : csub(sb[k] + cb[k], K.q);
+    }
+}
+
+// util/src/avec.rs:34-50 on a register-resident polynomial: scatter through the wave's LDS image
+template <int LOG_N>
+__device__ __forceinline__ void wave_automorphism(u64 (&c)[1 << (LOG_N - 6)], unsigned t, int lane, u64 *lds, u64 q) {
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E, N = W::N;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const unsigned i = coef_index<LOG_N>(lane, k);
+        const unsigned it = (i * t) & (2 * N - 1);
+        const u64 v = c[k];
+        lds[lds_phys(it & (N - 1))] = it < N ? v : (v ? q - v : 0);
+    }
+    exchange_sync<true>();
+#pragma unroll
+    for (int k = 0; k < E; ++k) c[k] = lds[lds_phys(coef_index<LOG_N>(lane, k))];
+    exchange_sync<true>();
+}
+
+template <int LOG_N>
+__device__ __forceinline__ void wave_load(u64 (&c)[1 << (LOG_N - 6)], const u64 *__restrict__ g, int lane) {
+#pragma unroll
+    for (int k = 0; k < (1 << (LOG_N - 6)); ++k) c[k] = g[coef_index<LOG_N>(lane, k)];
+}
+template <int LOG_N>
+__device__ __forceinline__ void wave_store(const u64 (&c)[1 << (LOG_N - 6)], u64 *__restrict__ g, int lane) {
+#pragma unroll
+    for (int k = 0; k < (1 << (LOG_N - 6)); ++k) g[coef_index<LOG_N>(lane, k)] = c[k];
+}
+
+constexpr int FHEW_WAVES_PER_BLOCK = 4;
+
+struct FhewKey {      // device view of a prepared gadget key set
+    const u64 *rows;  // [count][rows_per_ct][2][N] evaluation domain, key_perm layout
+    int rows_per_ct;  // 2d (RGSW) or d (key-switching key)
+    DecompParams P;
+};
+
+// batched gadget product, every ciphertext against key entry `index`:
+//   both = 1: RLWE x RGSW external product; both = 0: RLWE key switch, preceded by X -> X^t2n when t2n != 1
+//   (scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism`)
+template <int LOG_N>
+__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void gadget_product_kernel(
+    u64 *__restrict__ ct_a, u64 *__restrict__ ct_b, unsigned batch, FhewKey key, unsigned index, unsigned both, unsigned t2n,
+    RingConsts K) {
+    using W = WaveRing<LOG_N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
+    if (ct >= batch) return;  // wave-uniform exit; no workgroup barrier is used anywhere
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    u64 ca[W::E], cb[W::E];
+    wave_load<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
+    wave_load<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
+    if (t2n != 1) {
+        wave_automorphism<LOG_N>(ca, t2n, lane, lds, K.q);
+        wave_automorphism<LOG_N>(cb, t2n, lane, lds, K.q);
+    }
+    wave_gadget_product<LOG_N>(ca, cb, key.rows + size_t(index) * key.rows_per_ct * 2 * W::N, key.P, both != 0, lane, lds, K);
+    wave_store<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
+    wave_store<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
+}
+
+// evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout
+template <int LOG_N>
+__global__ void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
+    constexpr int N = 1 << LOG_N;
+    const size_t total = rows * N;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t row = idx >> LOG_N;
+        const int e = int(idx & (N - 1));
+        const int p = key_perm<LOG_N>(e);
+        out[(row * 2 + 0) * N + p] = in_a[idx];
+        out[(row * 2 + 1) * N + p] = in_b[idx];
+    }
+}
+
+// ---- LMKCDEY blind rotation (scheme/fhew/src/bootstrapping.rs:158-231) --------------------------
+// op list entry: bit 31 = 1 -> automorphism with ak[idx], else external product with brk[idx]
+constexpr unsigned BR_OP_AK = 0x80000000u;
+
+// One thread per ciphertext restates i_minus_i_plus + the walk of blind_rotate_core into an op list.
+// dlog[x] for x in [0, 2N): (l << 1) | sign (sign 1 = "minus" map), 0xffffffff if x is not +-5^l (even x)
+__global__ void blind_rotate_schedule_kernel(const u64 *__restrict__ lwe_a, unsigned n_lwe, unsigned batch, unsigned n, unsigned w,
+                                             const unsigned *__restrict__ dlog, unsigned *__restrict__ ops, unsigned *__restrict__ nops,
+                                             unsigned max_ops, unsigned *__restrict__ scratch /* [batch][2 * n_lwe + n + 2] */,
+                                             int *__restrict__ err) {
+    const unsigned ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= batch) return;
+    const unsigned half = n / 2;
+    const u64 *a = lwe_a + size_t(ct) * n_lwe;
+    unsigned *cnt = scratch + size_t(ct) * (2 * n_lwe + n + 2);  // [2][half+1] bucket starts
+    unsigned *sorted = cnt + n + 2;                                // [2][n_lwe] indices grouped by (sign, l), index order kept
+    unsigned *out = ops + size_t(ct) * max_ops;
+    for (unsigned i = 0; i < n + 2; ++i) cnt[i] = 0;
+    // bucket sizes; sign 1 = i_minus, sign 0 = i_plus
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const u64 ai = a[i];
+        if (ai >= 2 * n) { *err = 1; continue; }
+        if (ai == 0) continue;  // bootstrapping.rs:220
+        const unsigned e = dlog[ai];
+        if (e == 0xffffffffu) { *err = 2; continue; }  // even a_i: `unreachable!()` in the reference
+        cnt[(e & 1) * (half + 1) + (e >> 1) + 1]++;
+    }
+    for (unsigned s = 0; s < 2; ++s)
+        for (unsigned l = 0; l < half; ++l) cnt[s * (half + 1) + l + 1] += cnt[s * (half + 1) + l];
+    // stable fill (cnt[..l] is the running write position of bucket l; restore by walking back afterwards)
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const u64 ai = a[i];
+        if (ai == 0 || ai >= 2 * n) continue;
+        const unsigned e = dlog[ai];
+        if (e == 0xffffffffu) continue;
+        const unsigned s = e & 1, l = e >> 1;
+        sorted[s * n_lwe + cnt[s * (half + 1) + l]++] = i;
+    }
+    // after the fill cnt[s][l] == end of bucket l == start of bucket l+1; start of bucket l is cnt[s][l-1] (0 for l = 0)
+    unsigned k = 0, v = 0;
+    auto emit_bucket = [&](unsigned s, unsigned l) {
+        const unsigned lo = l ? cnt[s * (half + 1) + l - 1] : 0, hi = cnt[s * (half + 1) + l];
+        for (unsigned j = lo; j < hi && k < max_ops; ++j) out[k++] = sorted[s * n_lwe + j];
+    };
+    auto bucket_nonempty = [&](unsigned s, unsigned l) {
+        const unsigned lo = l ? cnt[s * (half + 1) + l - 1] : 0, hi = cnt[s * (half + 1) + l];
+        return hi > lo;
+    };
+    for (unsigned l = half - 1; l >= 1; --l) {  // bootstrapping.rs:181-190 (i_minus)
+        emit_bucket(1, l);
+        ++v;
+        if (bucket_nonempty(1, l - 1) || v == w || l == 1) { if (k < max_ops) out[k++] = BR_OP_AK | v; v = 0; }
+    }
+    emit_bucket(1, 0);                           // 191-193
+    if (k < max_ops) out[k++] = BR_OP_AK | 0;    // 194
+    for (unsigned l = half - 1; l >= 1; --l) {  // 195-204 (i_plus)
+        emit_bucket(0, l);
+        ++v;
+        if (bucket_nonempty(0, l - 1) || v == w || l == 1) { if (k < max_ops) out[k++] = BR_OP_AK | v; v = 0; }
+    }
+    emit_bucket(0, 0);                           // 205-207
+    nops[ct] = k;
+}
+
+struct BlindRotateParams {
+    FhewKey brk;          // n_lwe RGSW ciphertexts (2d rows each)
+    FhewKey ak;           // w + 1 automorphism keys (d_ks rows each)
+    const unsigned *ak_t; // [w + 1] exponents mod 2N
+    const unsigned *ops;  // [batch][max_ops]
+    const unsigned *nops; // [batch]
+    unsigned max_ops;
+    const u64 *lwe_b;     // [batch] mod 2N
+    const u64 *f;         // LUT polynomial(s)
+    size_t f_stride;      // 0: one f for the whole batch, N: one per ciphertext
+};
+
+template <int LOG_N>
+__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
+                                                                                  u64 *__restrict__ out_b, unsigned batch, RingConsts K) {
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E, N = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    u64 ca[E], cb[E];
+    // acc = (0, f.automorphism(-g) * X^(b*g))   (bootstrapping.rs:165-167); both steps are signed index maps
+    {
+        const u64 *f = BR.f + size_t(ct) * BR.f_stride;
+        const unsigned b = unsigned(BR.lwe_b[ct] & (2 * N - 1));
+        const unsigned kmono = (b * 5u) & (2 * N - 1);  // (b * g) mod 2N; X^k with k taken mod 2N
+        const unsigned tneg = (2 * N - 5u) & (2 * N - 1);
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const unsigned i = coef_index<LOG_N>(lane, k);
+            const u64 v = f[i];
+            unsigned pos = (i * tneg) & (2 * N - 1);   // automorphism(-5): X^i -> X^(i t)
+            pos = (pos + kmono) & (2 * N - 1);         // * X^k
+            lds[lds_phys(pos & (N - 1))] = pos < N ? v : (v ? K.q - v : 0);
+        }
+        exchange_sync<true>();
+#pragma unroll
+        for (int k = 0; k < E; ++k) { cb[k] = lds[lds_phys(coef_index<LOG_N>(lane, k))]; ca[k] = 0; }
+        exchange_sync<true>();
+    }
+    const unsigned *ops = BR.ops + size_t(ct) * BR.max_ops;
+    const unsigned nops = BR.nops[ct];
+    for (unsigned o = 0; o < nops; ++o) {
+        const unsigned op = __builtin_amdgcn_readfirstlane(ops[o]);
+        const bool is_ak = (op & BR_OP_AK) != 0;
+        const unsigned idx = op & 0x7fffffffu;
+        if (is_ak) {
+            const unsigned t = BR.ak_t[idx];
+            wave_automorphism<LOG_N>(ca, t, lane, lds, K.q);
+            wave_automorphism<LOG_N>(cb, t, lane, lds, K.q);
+        }
+        const FhewKey &key = is_ak ? BR.ak : BR.brk;
+        wave_gadget_product<LOG_N>(ca, cb, key.rows + size_t(idx) * key.rows_per_ct * 2 * N, key.P, !is_ak, lane, lds, K);
+    }
+    wave_store<LOG_N>(ca, out_a + size_t(ct) * N, lane);
+    wave_store<LOG_N>(cb, out_b + size_t(ct) * N, lane);
+}
+
+}  // namespace fhe

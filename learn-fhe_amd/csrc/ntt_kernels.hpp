@@ -99,10 +99,21 @@ __device__ __forceinline__ int pass_top(int grp) {
     return top;
 }
 
+// exchange-point synchronisation: a workgroup barrier when several waves share the polynomial, only an LDS
+// drain when ONE wave owns it (LDS operations of a single wave complete in order)
+template <bool WAVE>
+__device__ __forceinline__ void exchange_sync() {
+    if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    else __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward transform: passes run L0 = 0, R0, R0+LOG_E, ...
+// REGS_IO: the caller supplies x[] in the first pass's layout (pass_index<LOG_N,0,R0>(t + T*gg, r) at
+// x[gg*2^R0 + r]) and gets the evaluations back in x[] in the last pass's layout (coefficient t*E + r at
+// x[r]), still lazy in [0, 4q); nothing touches global memory.
 // ---------------------------------------------------------------------------------------------
-template <typename C, int LOG_N, int LOG_E, int L0>
+template <typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false>
 __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
                                         const TwPair *__restrict__ tw, u64 q, u64 q2) {
     constexpr int E = 1 << LOG_E;
@@ -116,8 +127,11 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
         for (int r = 0; r < (1 << R); ++r) {
             const int i = pass_index<LOG_N, L0, R>(grp, r);
-            if constexpr (first) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
-            else x[gg * (1 << R) + r] = lds[lds_phys(i)];
+            if constexpr (first) {
+                if constexpr (!REGS_IO) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
+            } else {
+                x[gg * (1 << R) + r] = lds[lds_phys(i)];
+            }
         }
     }
     // butterflies
@@ -129,7 +143,9 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #endif
     });
     // store
-    if constexpr (last && C::P == 1) {
+    if constexpr (last && REGS_IO) {
+        return;
+    } else if constexpr (last && C::P == 1) {
 #pragma unroll
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
@@ -144,8 +160,8 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
                 if constexpr (last) v = canon4(v, q, q2);
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = v;
             }
-        __syncthreads();
-        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R>(x, t, g, lds, active, tw, q, q2);
+        exchange_sync<WAVE>();
+        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R, REGS_IO, WAVE>(x, t, g, lds, active, tw, q, q2);
     }
 }
 
@@ -177,7 +193,9 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 // ---------------------------------------------------------------------------------------------
 // inverse transform: passes run from the last layers back to layer 0
 // ---------------------------------------------------------------------------------------------
-template <typename C, int LOG_N, int LOG_E, int LEND>  // this pass covers layers [L0, LEND)
+// REGS_IO: x[] comes in in the last-layer pass layout (coefficient t*E + r at x[r], values in [0, 2q)) and
+// leaves in the first-pass layout, multiplied by n^-1 and canonical.
+template <typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false>  // layers [L0, LEND)
 __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
                                         const TwPair *__restrict__ twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
     constexpr int E = 1 << LOG_E;
@@ -191,8 +209,13 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
         for (int r = 0; r < (1 << R); ++r) {
             const int i = pass_index<LOG_N, L0, R>(grp, r);
-            if constexpr (C::P == 1) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
-            else x[gg * (1 << R) + r] = lds[lds_phys(i)];
+            if constexpr (REGS_IO && LEND == LOG_N) {
+                (void)i;
+            } else if constexpr (C::P == 1) {
+                x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
+            } else {
+                x[gg * (1 << R) + r] = lds[lds_phys(i)];
+            }
         }
     }
     static_for<0, G>([&](auto gg_c) {
@@ -209,7 +232,8 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
                 const u64 v = csub(mul_shoup_lazy(x[gg * (1 << R) + r], ninv, ninv_s, q), q);
-                if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), v);
+                if constexpr (REGS_IO) x[gg * (1 << R) + r] = v;
+                else if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), v);
             }
     } else {
 #pragma unroll
@@ -217,8 +241,8 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r)
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = x[gg * (1 << R) + r];
-        __syncthreads();
-        inv_run<C, LOG_N, LOG_E, L0>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+        exchange_sync<WAVE>();
+        inv_run<C, LOG_N, LOG_E, L0, REGS_IO, WAVE>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
     }
 }
 
@@ -246,7 +270,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
 }
 
 // a[i] <- a[i] * b[i] mod q (evaluation-domain product, util/src/ring.rs:266-270)
-__global__ void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t len, Barrett B) {
+static __global__ void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t len, Barrett B) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < len; i += size_t(gridDim.x) * blockDim.x)
         a[i] = mulmod_barrett(a[i], b[i], B);
 }

@@ -5,26 +5,13 @@
 #include <new>
 
 #include "../../include/fhe_ring.h"
+#include "api_common.hpp"
 #include "ctx.hpp"
 #include "ntt_kernels.hpp"
 
 using fhe::u64;
 
 namespace {
-thread_local int g_last_hip = 0;
-
-#define HIP_TRY(expr)                         \
-    do {                                      \
-        hipError_t e_ = (expr);               \
-        if (e_ != hipSuccess) {               \
-            g_last_hip = (int)e_;             \
-            return FHE_ERR_HIP;               \
-        }                                     \
-    } while (0)
-
-inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
-inline int ilog2(size_t n) { return 63 - __builtin_clzll((unsigned long long)n); }
-
 // validates (ctx, n) the way the reference would panic
 int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
     if (!ctx || !is_pow2(n) || (!a && batch)) return FHE_ERR_INVALID;
@@ -34,21 +21,6 @@ int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
     if (log_n > ctx->log_cap) return FHE_ERR_UNSUPPORTED;
     return FHE_OK;
 }
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        hipError_t e = hipGetDevice(&prev);
-        if (e != hipSuccess) prev = -1;
-        if (prev != dev) e = hipSetDevice(dev);
-        if (e != hipSuccess) { ok = false; g_last_hip = (int)e; }
-        if (prev == dev) prev = -1;  // nothing to restore
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 template <int LOG_N, int LOG_E, int PPW>
 int launch_fwd(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
@@ -103,24 +75,12 @@ int dispatch_inv(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t 
     NTT_DISPATCH(launch_inv, log_n, c, a, batch, st)
 }
 
-// host-memory convenience path: stage through a temporary device buffer
-template <typename F>
-int with_staging(const fhe_ctx *ctx, uint64_t *a, size_t count, hipStream_t st, F &&body) {
-    u64 *d = nullptr;
-    HIP_TRY(hipMalloc(&d, count * sizeof(u64)));
-    int rc = FHE_OK;
-    if (hipMemcpyAsync(d, a, count * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
-    if (rc == FHE_OK) rc = body(d);
-    if (rc == FHE_OK && hipMemcpyAsync(a, d, count * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess)
-        rc = FHE_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
-    (void)hipFree(d);
-    (void)ctx;
-    return rc;
-}
 }  // namespace
 
 namespace fhe {
+
+int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return dispatch_fwd(c, a, log_n, batch, st); }
+int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return dispatch_inv(c, a, log_n, batch, st); }
 
 int ctx_build_host(uint64_t q, fhe_ctx *c) {
     if (q < 3) return FHE_ERR_INVALID;
@@ -238,7 +198,7 @@ int fhe_ctx_twiddles(const fhe_ctx *c, int inverse, uint64_t *out, size_t count)
     return FHE_OK;
 }
 
-int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+static int transform_entry(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream, bool inverse) {
     int rc = check_transform(ctx, a, n, batch);
     if (rc != FHE_OK) return rc;
     if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
@@ -247,46 +207,41 @@ int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return FHE_ERR_HIP;
-    const int log_n = ilog2(n);
-    if (mem == FHE_MEM_DEVICE) return dispatch_fwd(ctx, (u64 *)a, log_n, batch, st);
-    return with_staging(ctx, a, n * batch, st, [&](u64 *d) { return dispatch_fwd(ctx, d, log_n, batch, st); });
+    Mirror m(a, n * batch, mem, true, st);
+    if (m.rc != FHE_OK) return m.rc;
+    rc = inverse ? dispatch_inv(ctx, m.d, ilog2(n), batch, st) : dispatch_fwd(ctx, m.d, ilog2(n), batch, st);
+    if (rc != FHE_OK) return rc;
+    return m.sync_out(st);
+}
+
+int fhe_ntt_fwd(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return transform_entry(ctx, a, n, batch, mem, stream, false);
 }
 
 int fhe_ntt_inv(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
-    int rc = check_transform(ctx, a, n, batch);
-    if (rc != FHE_OK) return rc;
-    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
-    if (n == 1 || batch == 0) return FHE_OK;
-    if (batch > 0xffffffffull) return FHE_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    DeviceGuard guard(ctx->device);
-    if (!guard.ok) return FHE_ERR_HIP;
-    const int log_n = ilog2(n);
-    if (mem == FHE_MEM_DEVICE) return dispatch_inv(ctx, (u64 *)a, log_n, batch, st);
-    return with_staging(ctx, a, n * batch, st, [&](u64 *d) { return dispatch_inv(ctx, d, log_n, batch, st); });
+    return transform_entry(ctx, a, n, batch, mem, stream, true);
+}
+
+static int launch_pointwise(const fhe_ctx *ctx, u64 *a, const u64 *b, size_t len, hipStream_t st) {
+    size_t blocks = (len + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fhe::pointwise_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, len, ctx->barrett);
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
 }
 
 int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t len, fhe_mem mem, void *stream) {
-    if (!ctx || !a || !b) return FHE_ERR_INVALID;
+    if (!ctx || ((!a || !b) && len)) return FHE_ERR_INVALID;
     if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
     if (len == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return FHE_ERR_HIP;
-    auto run = [&](u64 *da, const u64 *db) -> int {
-        size_t blocks = (len + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(fhe::pointwise_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, da, db, len, ctx->barrett);
-        HIP_TRY(hipGetLastError());
-        return FHE_OK;
-    };
-    if (mem == FHE_MEM_DEVICE) return run((u64 *)a, (const u64 *)b);
-    u64 *db = nullptr;
-    HIP_TRY(hipMalloc(&db, len * sizeof(u64)));
-    int rc = hipMemcpyAsync(db, b, len * sizeof(u64), hipMemcpyHostToDevice, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
-    if (rc == FHE_OK) rc = with_staging(ctx, a, len, st, [&](u64 *da) { return run(da, db); });
-    (void)hipFree(db);
-    return rc;
+    Mirror ma(a, len, mem, true, st), mb(b, len, mem, true, st);
+    if (ma.rc != FHE_OK || mb.rc != FHE_OK) return FHE_ERR_HIP;
+    int rc = launch_pointwise(ctx, ma.d, mb.d, len, st);
+    if (rc != FHE_OK) return rc;
+    return ma.sync_out(st);
 }
 
 int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
@@ -302,30 +257,20 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
     if (!guard.ok) return FHE_ERR_HIP;
     const size_t count = n * batch;
     const int log_n = ilog2(n);
+    Mirror ma(a, count, mem, true, st);
+    if (ma.rc != FHE_OK) return ma.rc;
     // b is const: transform a scratch copy (the reference allocates one too, fft/zq.rs:21-25)
     u64 *tb = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&tb, count * sizeof(u64), st));
-    auto run = [&](u64 *da) -> int {
-        int r = FHE_OK;
-        if (n > 1) r = dispatch_fwd(ctx, da, log_n, batch, st);
-        if (r == FHE_OK && n > 1) r = dispatch_fwd(ctx, tb, log_n, batch, st);
-        if (r == FHE_OK) {
-            size_t blocks = (count + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(fhe::pointwise_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, da, (const u64 *)tb,
-                               count, ctx->barrett);
-            if (hipGetLastError() != hipSuccess) r = FHE_ERR_HIP;
-        }
-        if (r == FHE_OK && n > 1) r = dispatch_inv(ctx, da, log_n, batch, st);
-        return r;
-    };
+    HIP_TRY(hipMalloc((void **)&tb, count * sizeof(u64)));
     hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
-    if (rc == FHE_OK) {
-        if (mem == FHE_MEM_DEVICE) rc = run((u64 *)a);
-        else rc = with_staging(ctx, a, count, st, run);
-    }
-    (void)hipFreeAsync(tb, st);
+    if (rc == FHE_OK && n > 1) rc = dispatch_fwd(ctx, ma.d, log_n, batch, st);
+    if (rc == FHE_OK && n > 1) rc = dispatch_fwd(ctx, tb, log_n, batch, st);
+    if (rc == FHE_OK) rc = launch_pointwise(ctx, ma.d, tb, count, st);
+    if (rc == FHE_OK && n > 1) rc = dispatch_inv(ctx, ma.d, log_n, batch, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // tb must outlive the launches
+    (void)hipFree(tb);
     return rc;
 }
 

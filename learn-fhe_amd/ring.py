@@ -76,3 +76,123 @@ class NttContext:
         assert cnt == cntb and mem == memb
         L.check(L.lib().fhe_pointwise_mul(self._h, pa, pb, cnt, mem, st), "fhe_pointwise_mul")
         return a
+
+
+# ---- rows a8-a13: decomposition, automorphism, gadget keys, blind rotation -------------------------------
+
+
+def _like(x, shape):
+    if _is_torch(x):
+        import torch
+        return torch.empty(shape, dtype=x.dtype, device=x.device)
+    return np.empty(shape, dtype=np.uint64)
+
+
+def decompose(q, log_b, d, a, n):
+    """util/src/misc/decompose.rs:42-46: [polys][n] -> [polys][d][n]."""
+    p, cnt, mem, st = _buf(a)
+    polys = cnt // n
+    out = _like(a, (polys, d, n))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_decompose(q, log_b, d, p, n, polys, po, mem, st), "fhe_decompose")
+    return out
+
+
+def automorphism(q, t, a, n):
+    """util/src/avec.rs:34-50."""
+    p, cnt, mem, st = _buf(a)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_automorphism(q, t, p, po, n, cnt // n, mem, st), "fhe_automorphism")
+    return out
+
+
+def monomial_mul(q, k, a, n):
+    """util/src/ring.rs:299-313."""
+    p, cnt, mem, st = _buf(a)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_monomial_mul(q, k, p, po, n, cnt // n, mem, st), "fhe_monomial_mul")
+    return out
+
+
+class GadgetKey:
+    """Prepared (evaluation-domain, device-resident) RGSW ciphertexts or RLWE key-switching keys."""
+
+    def __init__(self, ctx: NttContext, log_b, d, rows_a, rows_b, n, rgsw: bool):
+        self.ctx, self.log_b, self.d, self.n, self.rgsw = ctx, log_b, d, n, rgsw
+        pa, cnt, mem, _ = _buf(rows_a)
+        pb, cntb, memb, _ = _buf(rows_b)
+        rows = (2 * d if rgsw else d)
+        assert cnt == cntb and mem == memb and cnt % (rows * n) == 0
+        self.count = cnt // (rows * n)
+        self._h = C.c_void_p()
+        fn = L.lib().fhe_rgsw_prepare if rgsw else L.lib().fhe_ksk_prepare
+        L.check(fn(ctx.handle, log_b, d, pa, pb, n, self.count, mem, C.byref(self._h)), "fhe_%s_prepare" % ("rgsw" if rgsw else "ksk"))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_key_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def external_product_(self, index, ct_a, ct_b):
+        """scheme/fhew/src/rgsw.rs:116-128, in place on [batch][n] a/b."""
+        pa, cnt, mem, st = _buf(ct_a)
+        pb, _, _, _ = _buf(ct_b)
+        L.check(L.lib().fhe_external_product(self.ctx.handle, self._h, index, pa, pb, cnt // self.n, mem, st), "fhe_external_product")
+
+    def key_switch_(self, index, ct_a, ct_b):
+        """scheme/fhew/src/rlwe.rs:177-186."""
+        pa, cnt, mem, st = _buf(ct_a)
+        pb, _, _, _ = _buf(ct_b)
+        L.check(L.lib().fhe_rlwe_key_switch(self.ctx.handle, self._h, index, pa, pb, cnt // self.n, mem, st), "fhe_rlwe_key_switch")
+
+    def automorphism_(self, index, t, ct_a, ct_b):
+        """scheme/fhew/src/rlwe.rs:188-191."""
+        pa, cnt, mem, st = _buf(ct_a)
+        pb, _, _, _ = _buf(ct_b)
+        L.check(L.lib().fhe_rlwe_automorphism(self.ctx.handle, self._h, index, t, pa, pb, cnt // self.n, mem, st),
+                "fhe_rlwe_automorphism")
+
+
+class BootstrapKey:
+    """scheme/fhew/src/bootstrapping.rs:93-113 (brk + ak part)."""
+
+    def __init__(self, ctx: NttContext, brk: GadgetKey, ak: GadgetKey, ak_t, w):
+        self.ctx, self.brk, self.ak, self.w = ctx, brk, ak, w
+        t = (C.c_int64 * len(ak_t))(*ak_t)
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_bootstrap_key_create(ctx.handle, brk.handle, ak.handle, t, w, C.byref(self._h)), "fhe_bootstrap_key_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_bootstrap_key_destroy(h)
+
+    def blind_rotate(self, lwe_a, lwe_b, f, want_schedule=False):
+        """scheme/fhew/src/bootstrapping.rs:158-209 for a batch: lwe_a [batch][n_lwe], lwe_b [batch], f [n] or [batch][n]."""
+        n, n_lwe = self.brk.n, self.brk.count
+        pa, cnt, mem, st = _buf(lwe_a)
+        pb, batch, _, _ = _buf(lwe_b)
+        pf, fcnt, _, _ = _buf(f)
+        assert cnt == batch * n_lwe and fcnt in (n, n * batch)
+        out_a, out_b = _like(lwe_a, (batch, n)), _like(lwe_a, (batch, n))
+        poa, _, _, _ = _buf(out_a)
+        pob, _, _, _ = _buf(out_b)
+        ops = nops = None
+        po = pn = None
+        if want_schedule:
+            max_ops = n_lwe + n + 2
+            ops = np.zeros((batch, max_ops), dtype=np.uint32)
+            nops = np.zeros(batch, dtype=np.uint32)
+            po, pn = ops.ctypes.data_as(C.POINTER(C.c_uint32)), nops.ctypes.data_as(C.POINTER(C.c_uint32))
+        L.check(L.lib().fhe_blind_rotate(self._h, pa, pb, pf, 0 if fcnt == n else n, poa, pob, batch, mem, st, po, pn),
+                "fhe_blind_rotate")
+        if want_schedule:
+            sched = [[("ak" if int(o) >> 31 else "ep", int(o) & 0x7FFFFFFF) for o in ops[i, :nops[i]]] for i in range(batch)]
+            return out_a, out_b, sched
+        return out_a, out_b

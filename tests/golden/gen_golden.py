@@ -97,7 +97,7 @@ def automorphism_vectors():
 def rlwe_vectors():
     """uniform-random key rows: noise/validity is irrelevant for bit parity."""
     rng = P.SplitMix64(5)
-    n, log_b, d = 64, 6, 3
+    n, log_b, d = 128, 6, 3
     q = next(P.two_adic_primes(54, 11))
     dec = P.Base2Decomposor(q, log_b, d)
     ra = [rng.uniform(q, n) for _ in range(2 * d)]
@@ -115,7 +115,7 @@ def rlwe_vectors():
 
 def blind_rotate_vector():
     rng = P.SplitMix64(6)
-    n, log_b, d, w, n_lwe = 32, 6, 3, 3, 6
+    n, log_b, d, w, n_lwe = 128, 6, 3, 3, 6
     q = next(P.two_adic_primes(54, 11))
     dec = P.Base2Decomposor(q, log_b, d)
     brk = [([rng.uniform(q, n) for _ in range(2 * d)], [rng.uniform(q, n) for _ in range(2 * d)]) for _ in range(n_lwe)]

@@ -1,0 +1,263 @@
+"""GPU parity tests for SURVEY.md section 8(a) rows a8-a13 through the C ABI, bit-exact against the oracle
+(oracle/cref.py, oracle/pyref.py) on identical seeded inputs and against the committed golden vectors."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+L = lambda x: [int(v) for v in np.asarray(x).ravel()]  # noqa: E731
+
+
+def rand_u64(seed, q, shape):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, q, size=shape, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_decompose_golden_and_oracle(fhe, cref, torch_cuda):
+    for v in load_golden("decompose.json"):
+        a = np.array(v["in"], dtype=np.uint64)
+        n = a.size
+        out = fhe.decompose(v["q"], v["log_b"], v["d"], dev(torch_cuda, a), n)
+        assert host(out).reshape(v["d"], n).tolist() == v["digits"]
+        out_h = fhe.decompose(v["q"], v["log_b"], v["d"], a, n)  # host-memory entry path
+        assert out_h.reshape(v["d"], n).tolist() == v["digits"]
+    for bits, log_n, log_b, d in [(28, 10, 7, 4), (54, 10, 6, 9), (45, 10, 5, 9), (55, 12, 11, 5), (60, 15, 12, 5)]:
+        q = cref.two_adic_primes(bits, log_n, 1)[0]
+        n, polys = 256, 5
+        a = rand_u64(bits, q, (polys, n))
+        a[0, :6] = [0, 1, q - 1, q >> 1, (q >> 1) - 1, (q >> 1) + 1]
+        out = host(fhe.decompose(q, log_b, d, dev(torch_cuda, a), n))
+        for p in range(polys):
+            assert np.array_equal(out[p], cref.decompose(q, log_b, d, a[p]))
+    q = 1 << 16  # non-prime modulus (LWE key switch)
+    a = rand_u64(3, q, (1, 100))
+    assert np.array_equal(host(fhe.decompose(q, 4, 4, dev(torch_cuda, a), 100))[0], cref.decompose(q, 4, 4, a[0]))
+
+
+def test_automorphism_monomial(fhe, cref, torch_cuda):
+    g = load_golden("automorphism.json")
+    for v in g["automorphism"]:
+        a = np.array(v["in"], dtype=np.uint64)
+        assert L(host(fhe.automorphism(v["q"], v["t"], dev(torch_cuda, a), a.size))) == v["out"]
+    for v in g["monomial"]:
+        a = np.array(v["in"], dtype=np.uint64)
+        assert L(host(fhe.monomial_mul(v["q"], v["k"], dev(torch_cuda, a), a.size))) == v["out"]
+    q = 18014398509404161
+    for n in (1, 2, 64, 1024):
+        a = rand_u64(n, q, (3, n))
+        a[0, 0] = 0
+        for t in (5, -5, 25, 1, -1, 2 * n - 1, 3, 2 * n + 5):
+            out = host(fhe.automorphism(q, t, dev(torch_cuda, a), n))
+            for p in range(3):
+                assert np.array_equal(out[p], cref.automorphism(q, t, a[p])), (n, t)
+        for k in (0, 1, -1, n, n - 1, n + 1, 2 * n - 1, -n, 3 * n + 5, -7):
+            out = host(fhe.monomial_mul(q, k, dev(torch_cuda, a), n))
+            for p in range(3):
+                assert np.array_equal(out[p], cref.monomial_mul(q, k, a[p])), (n, k)
+
+
+def test_gadget_products_golden(fhe, torch_cuda):
+    v = load_golden("rlwe.json")
+    q, n, lb, d = v["q"], v["n"], v["log_b"], v["d"]
+    ctx = fhe.NttContext(q)
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    rgsw = fhe.GadgetKey(ctx, lb, d, dev(torch_cuda, U(v["rgsw_a"])), dev(torch_cuda, U(v["rgsw_b"])), n, rgsw=True)
+    ksk = fhe.GadgetKey(ctx, lb, d, U(v["ksk_a"]), U(v["ksk_b"]), n, rgsw=False)  # host-memory key rows
+    a, b = dev(torch_cuda, U(v["ct_a"])), dev(torch_cuda, U(v["ct_b"]))
+    rgsw.external_product_(0, a, b)
+    assert L(host(a)) == v["ext_a"] and L(host(b)) == v["ext_b"]
+    a, b = dev(torch_cuda, U(v["ct_a"])), dev(torch_cuda, U(v["ct_b"]))
+    ksk.key_switch_(0, a, b)
+    assert L(host(a)) == v["ks_a"] and L(host(b)) == v["ks_b"]
+    a, b = U(v["ct_a"]).copy(), U(v["ct_b"]).copy()  # host-memory ciphertext
+    ksk.automorphism_(0, v["auto_t"], a, b)
+    assert L(a) == v["auto_a"] and L(b) == v["auto_b"]
+    with pytest.raises(fhe.FheError):  # an RGSW key is not a key-switching key
+        rgsw.key_switch_(0, dev(torch_cuda, U(v["ct_a"])), dev(torch_cuda, U(v["ct_b"])))
+
+
+@pytest.mark.parametrize("log_n,bits,log_b,d", [(7, 45, 5, 9), (8, 28, 7, 4), (9, 28, 7, 4), (10, 54, 6, 9), (11, 55, 11, 5)])
+def test_gadget_products_vs_oracle(fhe, cref, torch_cuda, log_n, bits, log_b, d):
+    """reference parameter sets (rgsw.rs:164-227 (5,9)@45; boolean.rs:225-239 (7,4)@28; cfg3 (6,9)@54; example (11,5)@55);
+    uniform-random key rows, ragged batch, two key entries"""
+    n = 1 << log_n
+    q = cref.two_adic_primes(bits, log_n + 1, 1)[0]
+    ctx = fhe.NttContext(q)
+    batch, count = 7, 2
+    ra, rb = rand_u64(1, q, (count, 2 * d, n)), rand_u64(2, q, (count, 2 * d, n))
+    ka, kb = rand_u64(3, q, (count, d, n)), rand_u64(4, q, (count, d, n))
+    ca, cb = rand_u64(5, q, (batch, n)), rand_u64(6, q, (batch, n))
+    ca[0, :4] = [0, q - 1, q >> 1, (q >> 1) + 1]
+    rgsw = fhe.GadgetKey(ctx, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n, rgsw=True)
+    ksk = fhe.GadgetKey(ctx, log_b, d, dev(torch_cuda, ka), dev(torch_cuda, kb), n, rgsw=False)
+    for idx in range(count):
+        a, b = dev(torch_cuda, ca), dev(torch_cuda, cb)
+        rgsw.external_product_(idx, a, b)
+        ha, hb = host(a), host(b)
+        for i in range(batch):
+            ea, eb = cref.external_product(q, log_b, d, ra[idx], rb[idx], ca[i], cb[i])
+            assert np.array_equal(ha[i], ea) and np.array_equal(hb[i], eb), (idx, i)
+        a, b = dev(torch_cuda, ca), dev(torch_cuda, cb)
+        ksk.key_switch_(idx, a, b)
+        ha, hb = host(a), host(b)
+        for i in range(0, batch, 3):
+            ea, eb = cref.rlwe_key_switch(q, log_b, d, ka[idx], kb[idx], ca[i], cb[i])
+            assert np.array_equal(ha[i], ea) and np.array_equal(hb[i], eb)
+        for t in (5, -5, 25):
+            a, b = dev(torch_cuda, ca), dev(torch_cuda, cb)
+            ksk.automorphism_(idx, t, a, b)
+            ha, hb = host(a), host(b)
+            ea, eb = cref.rlwe_automorphism(q, log_b, d, t, ka[idx], kb[idx], ca[1], cb[1])
+            assert np.array_equal(ha[1], ea) and np.array_equal(hb[1], eb)
+
+
+def test_external_product_decrypt_level(fhe, torch_cuda):
+    """scheme/fhew/src/rgsw.rs:198-211 on the GPU path: decrypt(rgsw(m0) [x] rlwe(m1)) == m0 * m1 (valid keys from the
+    oracle's key generator), and rlwe.rs:401-415 for the automorphism."""
+    from oracle import pyref as P
+    rnd = random.Random(21)
+    log_n, p, log_b, d = 7, 16, 5, 9
+    n = 1 << log_n
+    q = next(P.two_adic_primes(45, log_n + 1))
+    dec = P.Base2Decomposor(q, log_b, d)
+    delta = q / p
+    enc = lambda m: [P.zq_from_f64(q, float(x) * delta) for x in m]  # noqa: E731
+    decd = lambda pt: [P.zq_from_f64(p, float(P.zq_to_i64(q, x)) / delta) for x in pt]  # noqa: E731
+    sk = [rnd.randint(-3, 3) for _ in range(n)]
+    m0, m1 = [rnd.randrange(p) for _ in range(n)], [rnd.randrange(p) for _ in range(n)]
+    ra, rb = P.rgsw_encrypt(q, dec, sk, m0, rnd)
+    ca, cb = P.rlwe_sk_encrypt(q, sk, enc(m1), rnd)
+    ctx = fhe.NttContext(q)
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    rgsw = fhe.GadgetKey(ctx, log_b, d, U(ra), U(rb), n, rgsw=True)
+    a, b = dev(torch_cuda, U(ca)), dev(torch_cuda, U(cb))
+    rgsw.external_product_(0, a, b)
+    assert decd(P.rlwe_decrypt(q, sk, L(host(a)), L(host(b)))) == P.nega_cyclic_schoolbook_mul(p, m0, m1)
+    for t in (5, -5):
+        ka, kb = P.rlwe_ak_gen(q, dec, t, sk, rnd)
+        ak = fhe.GadgetKey(ctx, log_b, d, U(ka), U(kb), n, rgsw=False)
+        a, b = dev(torch_cuda, U(ca)), dev(torch_cuda, U(cb))
+        ak.automorphism_(0, t, a, b)
+        assert decd(P.rlwe_decrypt(q, sk, L(host(a)), L(host(b)))) == P.automorphism(p, m1, t)
+
+
+def _make_bk(fhe, torch_cuda, q, n, log_b, d, ks_log_b, ks_d, w, n_lwe, seed):
+    from oracle import pyref as P
+    brk = rand_u64(seed, q, (n_lwe, 2, 2 * d, n))          # [key][a|b][row][n] as the oracle takes it
+    ak = rand_u64(seed + 1, q, (w + 1, 2, ks_d, n))
+    ctx = fhe.NttContext(q)
+    gk = fhe.GadgetKey(ctx, log_b, d, dev(torch_cuda, brk[:, 0]), dev(torch_cuda, brk[:, 1]), n, rgsw=True)
+    ga = fhe.GadgetKey(ctx, ks_log_b, ks_d, dev(torch_cuda, ak[:, 0]), dev(torch_cuda, ak[:, 1]), n, rgsw=False)
+    ts = P.ak_t(n, w)
+    return ctx, fhe.BootstrapKey(ctx, gk, ga, ts, w), brk, ak, ts
+
+
+def test_blind_rotate_golden(fhe, torch_cuda):
+    v = load_golden("blind_rotate.json")
+    q, n, w, lb, d = v["q"], v["n"], v["w"], v["log_b"], v["d"]
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    brk, ak = U(v["brk"]), U(v["ak"])  # [key][a|b][row][n]
+    ctx = fhe.NttContext(q)
+    gk = fhe.GadgetKey(ctx, lb, d, dev(torch_cuda, brk[:, 0]), dev(torch_cuda, brk[:, 1]), n, rgsw=True)
+    ga = fhe.GadgetKey(ctx, lb, d, dev(torch_cuda, ak[:, 0]), dev(torch_cuda, ak[:, 1]), n, rgsw=False)
+    bk = fhe.BootstrapKey(ctx, gk, ga, v["ak_t"], w)
+    oa, ob, sched = bk.blind_rotate(dev(torch_cuda, U([v["lwe_a"]])), dev(torch_cuda, U([v["lwe_b"]])), dev(torch_cuda, U(v["f"])),
+                                    want_schedule=True)
+    assert sched[0] == [(k, i) for k, i in v["schedule"]]
+    assert L(host(oa)) == v["out_a"] and L(host(ob)) == v["out_b"]
+
+
+def test_blind_rotate_vs_oracle_small(fhe, cref, torch_cuda):
+    """N = 128, n_lwe = 6, w = 3: batch of 6 with zero coefficients, repeated buckets, per-ciphertext LUTs"""
+    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 128, 6, 3, 3, 6, 6
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, 5, 4, w, n_lwe, seed=50)
+    rng = np.random.Generator(np.random.PCG64(9))
+    lwe_a = (rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_a[1, 2] = 0
+    lwe_a[2, :] = lwe_a[2, 0]          # all in one bucket
+    lwe_a[3, :] = 0                    # nothing to rotate by: only the automorphism walk
+    lwe_a[4, :3] = 2 * n - lwe_a[4, 3:6]  # +- pairs
+    lwe_b = rng.integers(0, 2 * n, size=batch, dtype=np.uint64)
+    f = rand_u64(77, q, (batch, n))
+    oa, ob, sched = bk.blind_rotate(dev(torch_cuda, lwe_a), dev(torch_cuda, lwe_b), dev(torch_cuda, f), want_schedule=True)
+    ha, hb = host(oa), host(ob)
+    for i in range(batch):
+        assert sched[i] == cref.blind_rotate_schedule(n, w, lwe_a[i]), i
+        ea, eb = cref.blind_rotate(q, n, w, lb, d, 5, 4, brk, ak, ts, f[i], lwe_a[i], int(lwe_b[i]))
+        assert np.array_equal(ha[i], ea) and np.array_equal(hb[i], eb), i
+    # shared LUT
+    oa2, ob2 = bk.blind_rotate(dev(torch_cuda, lwe_a[:2]), dev(torch_cuda, lwe_b[:2]), dev(torch_cuda, f[0]))
+    assert np.array_equal(host(oa2)[0], ha[0]) and np.array_equal(host(ob2)[0], hb[0])
+    # an even (non-zero) LWE coefficient is `unreachable!()` in the reference (bootstrapping.rs:221)
+    bad = lwe_a.copy()
+    bad[0, 0] = 4
+    with pytest.raises(fhe.FheError):
+        bk.blind_rotate(dev(torch_cuda, bad), dev(torch_cuda, lwe_b), dev(torch_cuda, f))
+
+
+def test_blind_rotate_cfg3(fhe, cref, torch_cuda):
+    """BASELINE config 3: N = 2^10, q = 18014398509404161, base 2^6, d = 9, n = 100, w = 10 -- the full CMUX loop,
+    bit-exact against the oracle on 2 ciphertexts (uniform-random keys: validity is irrelevant for parity)."""
+    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 1024, 6, 9, 10, 100, 2
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, lb, d, w, n_lwe, seed=60)
+    rng = np.random.Generator(np.random.PCG64(10))
+    lwe_a = (rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_b = rng.integers(0, 2 * n, size=batch, dtype=np.uint64)
+    f = rand_u64(78, q, n)
+    oa, ob, sched = bk.blind_rotate(dev(torch_cuda, lwe_a), dev(torch_cuda, lwe_b), dev(torch_cuda, f), want_schedule=True)
+    for i in range(batch):
+        assert sched[i] == cref.blind_rotate_schedule(n, w, lwe_a[i])
+        n_ep = sum(1 for k, _ in sched[i] if k == "ep")
+        assert n_ep == n_lwe and len(sched[i]) > 200
+        ea, eb = cref.blind_rotate(q, n, w, lb, d, lb, d, brk, ak, ts, f, lwe_a[i], int(lwe_b[i]))
+        assert np.array_equal(host(oa)[i], ea) and np.array_equal(host(ob)[i], eb), i
+
+
+def test_blind_rotate_decrypt_level(fhe, torch_cuda):
+    """valid keys: the constant term of the rotated accumulator decrypts to f at the LWE phase"""
+    from oracle import pyref as P
+    rnd = random.Random(31)
+    log_n, log_b, d, w, n_lwe = 7, 5, 9, 3, 8
+    n = 1 << log_n
+    q = next(P.two_adic_primes(45, log_n + 1))
+    dec = P.Base2Decomposor(q, log_b, d)
+    z = [rnd.randint(-1, 1) for _ in range(n)]
+    s = [rnd.randint(-1, 1) for _ in range(n_lwe)]
+    one = [1] + [0] * (n - 1)
+    brk = [P.rgsw_encrypt(q, dec, z, P.monomial_mul(q, one, sj), rnd) for sj in s]
+    ts = P.ak_t(n, w)
+    ak = [P.rlwe_ak_gen(q, dec, t, z, rnd) for t in ts]
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    ctx = fhe.NttContext(q)
+    gk = fhe.GadgetKey(ctx, log_b, d, U([k[0] for k in brk]), U([k[1] for k in brk]), n, rgsw=True)
+    ga = fhe.GadgetKey(ctx, log_b, d, U([k[0] for k in ak]), U([k[1] for k in ak]), n, rgsw=False)
+    bk = fhe.BootstrapKey(ctx, gk, ga, ts, w)
+    f = [rnd.randrange(q >> 4) << 3 for _ in range(n)]
+    batch = 5
+    a = [[rnd.randrange(n) * 2 + 1 for _ in range(n_lwe)] for _ in range(batch)]
+    b = [rnd.randrange(2 * n) for _ in range(batch)]
+    oa, ob = bk.blind_rotate(dev(torch_cuda, U(a)), dev(torch_cuda, U(b)), dev(torch_cuda, U(f)))
+    for i in range(batch):
+        mu = (b[i] - sum(x * y for x, y in zip(a[i], s))) % (2 * n)
+        pt = P.rlwe_decrypt(q, z, L(host(oa)[i]), L(host(ob)[i]))
+        exp = f[mu] if mu < n else P.zq_neg(q, f[mu - n])
+        assert abs(P.zq_to_i64(q, (pt[0] - exp) % q)) < (1 << 30)
