@@ -126,6 +126,29 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
                      size_t f_stride, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream,
                      uint32_t *ops_out, uint32_t *nops_out);
 
+/* ---- RNS rings (CKKS) ------------------------------------------------------------------------------------ */
+typedef struct fhe_rns_ctx fhe_rns_ctx;   /* bases qs (L primes) and ps (K primes): util/src/ring/rns.rs:278-322 `Rns` */
+typedef struct fhe_ckks_key fhe_ckks_key; /* a key-switching key over qs ++ ps, evaluation domain, device resident */
+/* `Rns::new(qs).with_ps(ps)` both ways (Q->P for extend_bases, P->Q for rescale_k) plus one transform context per
+ * prime.  All L+K primes must be distinct (rns.rs:25, 84 asserts).  L, K <= 32. */
+int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int device, fhe_rns_ctx **out);
+void fhe_rns_ctx_destroy(fhe_rns_ctx *rns);
+/* util/src/ring/rns.rs:83-91 `RnsRq::extend_bases(ps)`: in [batch][L][n] over qs -> out [batch][K][n], the new
+ * p-limbs (fast base conversion with the reference's f64 rounding correction, rns.rs:331-345). */
+int fhe_rns_extend_bases(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                         void *stream);
+/* util/src/ring/rns.rs:103-118 `rescale_k(K)` of a polynomial over qs ++ ps: in [batch][L+K][n] -> out [batch][L][n]. */
+int fhe_rns_rescale_k(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                      void *stream);
+/* key-switching key (scheme/ckks/src/ckks.rs:86-88, 143-161): ksk_b, ksk_a [L+K][n], coefficient domain. */
+int fhe_ckks_ksk_prepare(const fhe_rns_ctx *rns, const uint64_t *ksk_b, const uint64_t *ksk_a, size_t n, fhe_mem mem,
+                         fhe_ckks_key **out);
+void fhe_ckks_key_destroy(fhe_ckks_key *key);
+/* scheme/ckks/src/ckks.rs:284-293 `Ckks::key_switch(param, ksk, CkksCiphertext(ct_b, ct_a))`, in place, for `batch`
+ * ciphertexts: ct_b, ct_a [batch][L][n] over qs, coefficient domain.  n up to 2^17. */
+int fhe_ckks_key_switch(const fhe_rns_ctx *rns, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch,
+                        fhe_mem mem, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

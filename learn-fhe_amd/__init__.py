@@ -5,5 +5,5 @@ sources in `csrc/`.  This Python package is only the harness-side binding used b
 it loads the library with ctypes and fails loudly if it is missing -- there is no CPU fallback.
 """
 from ._lib import FheError, build, lib, lib_path  # noqa: F401
-from .ring import (BootstrapKey, GadgetKey, NttContext, automorphism, decompose,  # noqa: F401
-                   monomial_mul)
+from .ring import (BootstrapKey, CkksKey, GadgetKey, NttContext, RnsContext, automorphism,  # noqa: F401
+                   decompose, monomial_mul)

@@ -84,6 +84,15 @@ def lib():
         L.fhe_bootstrap_key_destroy.argtypes = [vp]
         L.fhe_bootstrap_key_destroy.restype = None
         L.fhe_blind_rotate.argtypes = [vp, vp, vp, vp, sz, vp, vp, sz, ci, vp, u32p, u32p]
+        L.fhe_rns_ctx_create.argtypes = [u64p, ci, u64p, ci, ci, C.POINTER(vp)]
+        L.fhe_rns_ctx_destroy.argtypes = [vp]
+        L.fhe_rns_ctx_destroy.restype = None
+        L.fhe_rns_extend_bases.argtypes = [vp, vp, vp, sz, sz, ci, vp]
+        L.fhe_rns_rescale_k.argtypes = [vp, vp, vp, sz, sz, ci, vp]
+        L.fhe_ckks_ksk_prepare.argtypes = [vp, vp, vp, sz, ci, C.POINTER(vp)]
+        L.fhe_ckks_key_destroy.argtypes = [vp]
+        L.fhe_ckks_key_destroy.restype = None
+        L.fhe_ckks_key_switch.argtypes = [vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib
 

@@ -8,6 +8,7 @@
 
 #include "dev_arith.hpp"
 #include "modmath.hpp"
+#include "ntt_kernels.hpp"
 
 struct fhe_ctx {
     uint64_t q = 0;
@@ -20,9 +21,14 @@ struct fhe_ctx {
     fhe::Barrett barrett{};
     int device = -1;
     fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM
+    fhe::ModDesc *d_desc = nullptr;                 // this modulus as the kernels read it (1 entry)
+    fhe::ModDesc h_desc{};
 };
 
 namespace fhe {
 constexpr int MAX_LOG_N = 17;
 int ctx_build_host(uint64_t q, fhe_ctx *c);  // returns FHE_* status
+// batched transforms over `batch` polynomials of degree 2^log_n; polynomial p uses descs[p % n_desc]
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st);
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st);
 }  // namespace fhe

@@ -152,13 +152,13 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)],
         u64 x[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = decomp_next(st[k], P);
-        fwd_run<typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, K.tw, K.q, K.q2);
+        fwd_run<typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, TwSel{K.tw, 0, 0}, K.q, K.q2);
         mac_row<LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, K);
     }
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, K.twi, K.q, K.q2, K.ninv, K.ninv_s);
+        inv_run<typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, TwSel{K.twi, 0, 0}, K.q, K.q2, K.ninv, K.ninv_s);
 #pragma unroll
         for (int k = 0; k < E; ++k) { const u64 t = sa[k]; sa[k] = sb[k]; sb[k] = t; }
     }

@@ -34,6 +34,24 @@ struct NttCfg {
 
 __device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }
 
+// Twiddle selector of one transform: table + the sub-transform prefix.  A ring of degree 2^(LOG_N + pb) is
+// processed as one radix-2^pb pass over the whole polynomial followed by 2^pb independent sub-transforms of
+// size 2^LOG_N; sub-transform `prefix` continues at layer pb with twiddle index
+// 2^(l + pb) + (prefix << l) + i  (the reference's tw[m + i], util/src/ring/fft.rs:43-53, restricted to a block).
+struct TwSel {
+    const TwPair *tw;
+    int pb;
+    int prefix;
+};
+
+// per-modulus constants as the kernels read them from HBM (one entry per RNS limb)
+struct ModDesc {
+    u64 q;
+    const TwPair *tw, *twi;
+    u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
+    u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
+};
+
 // Developer-lab ablation hooks (tools/ntt_lab.hip); never defined in the product build.
 #ifdef FHE_ABLATE_NO_GLOBAL
 __device__ __forceinline__ u64 gload(const u64 *p, int i) { return (u64)i * 0x9E3779B97F4A7C15ull >> 4; }
@@ -63,13 +81,13 @@ __device__ __forceinline__ int pass_index(int grp, int r) {
 // in-register radix-2^R passes on x[OFF .. OFF + 2^R)
 // ---------------------------------------------------------------------------------------------
 template <int L0, int R, int OFF, int E>
-__device__ __forceinline__ void fwd_pass_regs(u64 (&x)[E], int top, const TwPair *__restrict__ tw, u64 q, u64 q2) {
+__device__ __forceinline__ void fwd_pass_regs(u64 (&x)[E], int top, const TwSel tw, u64 q, u64 q2) {
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int half = 1 << (R - 1 - k);
 #pragma unroll
         for (int b = 0; b < (1 << k); ++b) {
-            const TwPair p = tw[(1 << (L0 + k)) + (top << k) + b];
+            const TwPair p = tw.tw[(1 << (L0 + k + tw.pb)) + ((((tw.prefix << L0) | top)) << k) + b];
 #pragma unroll
             for (int j = 0; j < half; ++j) ct_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
         }
@@ -77,13 +95,13 @@ __device__ __forceinline__ void fwd_pass_regs(u64 (&x)[E], int top, const TwPair
 }
 
 template <int L0, int R, int OFF, int E>
-__device__ __forceinline__ void inv_pass_regs(u64 (&x)[E], int top, const TwPair *__restrict__ twi, u64 q, u64 q2) {
+__device__ __forceinline__ void inv_pass_regs(u64 (&x)[E], int top, const TwSel twi, u64 q, u64 q2) {
 #pragma unroll
     for (int k = R - 1; k >= 0; --k) {
         const int half = 1 << (R - 1 - k);
 #pragma unroll
         for (int b = 0; b < (1 << k); ++b) {
-            const TwPair p = twi[(1 << (L0 + k)) + (top << k) + b];
+            const TwPair p = twi.tw[(1 << (L0 + k + twi.pb)) + ((((twi.prefix << L0) | top)) << k) + b];
 #pragma unroll
             for (int j = 0; j < half; ++j) gs_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
         }
@@ -115,7 +133,7 @@ __device__ __forceinline__ void exchange_sync() {
 // ---------------------------------------------------------------------------------------------
 template <typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false>
 __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
-                                        const TwPair *__restrict__ tw, u64 q, u64 q2) {
+                                        const TwSel tw, u64 q, u64 q2) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (L0 == 0) ? C::R0 : LOG_E;
     constexpr int G = E >> R;  // butterfly groups per thread in this pass
@@ -165,14 +183,19 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
     }
 }
 
+// data: `subs` sub-polynomials of size 2^LOG_N, contiguous; sub s belongs to polynomial s >> pb (modulus descriptor
+// (s >> pb) % n_desc) and is its sub-transform number s & (2^pb - 1).  pb = 0: plain transforms.
 template <int LOG_N, int LOG_E, int PPW>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_kernel(
-    u64 *__restrict__ data, const TwPair *__restrict__ tw, u64 q, unsigned batch) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb) {
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
     const unsigned poly = blockIdx.x * PPW + pw;
-    const bool active = poly < batch;
+    const bool active = poly < subs;
+    const ModDesc &D = descs[((active ? poly : 0u) >> pb) % n_desc];
+    const u64 q = D.q;
+    const TwSel tw{D.tw, pb, int(poly & ((1u << pb) - 1))};
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
@@ -197,7 +220,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 // leaves in the first-pass layout, multiplied by n^-1 and canonical.
 template <typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false>  // layers [L0, LEND)
 __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
-                                        const TwPair *__restrict__ twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
+                                        const TwSel twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (LEND == C::R0) ? C::R0 : LOG_E;
     constexpr int L0 = LEND - R;
@@ -248,12 +271,17 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 
 template <int LOG_N, int LOG_E, int PPW>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_kernel(
-    u64 *__restrict__ data, const TwPair *__restrict__ twi, u64 q, unsigned batch, u64 ninv, u64 ninv_s) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb) {
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
     const unsigned poly = blockIdx.x * PPW + pw;
-    const bool active = poly < batch;
+    const bool active = poly < subs;
+    const ModDesc &D = descs[((active ? poly : 0u) >> pb) % n_desc];
+    const u64 q = D.q;
+    const TwSel twi{D.twi, pb, int(poly & ((1u << pb) - 1))};
+    // with pb > 0 the n^-1 scaling belongs to the closing radix-2^pb pass: multiply by 1 here
+    const u64 ninv = pb ? 1 : D.ninv[LOG_N], ninv_s = pb ? D.one_s : D.ninv_s[LOG_N];
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
@@ -267,6 +295,47 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
         __syncthreads();
     }
     inv_run<C, LOG_N, LOG_E, LOG_N>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+}
+
+// Opening radix-2^PB pass of a ring of degree 2^log_n (layers 0..PB-1 across the 2^PB blocks), one thread per
+// column; leaves canonical values.  Followed by ntt_fwd_kernel<log_n - PB, ...> with pb = PB.
+template <int PB>
+__global__ void ntt_big_fwd_pass(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned batch, int log_n) {
+    const int lc = log_n - PB;  // log2 of the column count
+    const size_t total = size_t(batch) << lc;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const unsigned poly = unsigned(idx >> lc);
+        const size_t low = idx & ((size_t(1) << lc) - 1);
+        const ModDesc &D = descs[poly % n_desc];
+        const u64 q = D.q, q2 = 2 * q;
+        u64 *g = data + (size_t(poly) << log_n) + low;
+        u64 x[1 << PB];
+#pragma unroll
+        for (int r = 0; r < (1 << PB); ++r) x[r] = g[size_t(r) << lc];
+        fwd_pass_regs<0, PB, 0, (1 << PB)>(x, 0, TwSel{D.tw, 0, 0}, q, q2);
+#pragma unroll
+        for (int r = 0; r < (1 << PB); ++r) g[size_t(r) << lc] = canon4(x[r], q, q2);
+    }
+}
+
+// Closing pass of the inverse: layers PB-1..0 across the blocks, then * n^-1 (util/src/ring/fft.rs:76)
+template <int PB>
+__global__ void ntt_big_inv_pass(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned batch, int log_n) {
+    const int lc = log_n - PB;
+    const size_t total = size_t(batch) << lc;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const unsigned poly = unsigned(idx >> lc);
+        const size_t low = idx & ((size_t(1) << lc) - 1);
+        const ModDesc &D = descs[poly % n_desc];
+        const u64 q = D.q, q2 = 2 * q;
+        u64 *g = data + (size_t(poly) << log_n) + low;
+        u64 x[1 << PB];
+#pragma unroll
+        for (int r = 0; r < (1 << PB); ++r) x[r] = g[size_t(r) << lc];
+        inv_pass_regs<0, PB, 0, (1 << PB)>(x, 0, TwSel{D.twi, 0, 0}, q, q2);
+#pragma unroll
+        for (int r = 0; r < (1 << PB); ++r) g[size_t(r) << lc] = csub(mul_shoup_lazy(x[r], D.ninv[log_n], D.ninv_s[log_n], q), q);
+    }
 }
 
 // a[i] <- a[i] * b[i] mod q (evaluation-domain product, util/src/ring.rs:266-270)

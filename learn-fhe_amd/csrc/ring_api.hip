@@ -23,26 +23,25 @@ int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
 }
 
 template <int LOG_N, int LOG_E, int PPW>
-int launch_fwd(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
+int launch_fwd(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
     auto k = fhe::ntt_fwd_kernel<LOG_N, LOG_E, PPW>;
     if (C::LDS_BYTES > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    unsigned grid = (unsigned)((batch + PPW - 1) / PPW);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, c->d_tw, (u64)c->q, (unsigned)batch);
+    unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
 
 template <int LOG_N, int LOG_E, int PPW>
-int launch_inv(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
+int launch_inv(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
     auto k = fhe::ntt_inv_kernel<LOG_N, LOG_E, PPW>;
     if (C::LDS_BYTES > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-    unsigned grid = (unsigned)((batch + PPW - 1) / PPW);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, c->d_twi, (u64)c->q, (unsigned)batch,
-                       (u64)c->ninv[LOG_N], (u64)c->ninv_s[LOG_N]);
+    unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
@@ -68,19 +67,55 @@ int launch_inv(const fhe_ctx *c, u64 *a, size_t batch, hipStream_t st) {
         default: return FHE_ERR_UNSUPPORTED;                  \
     }
 
-int dispatch_fwd(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) {
-    NTT_DISPATCH(launch_fwd, log_n, c, a, batch, st)
+int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, hipStream_t st) {
+    NTT_DISPATCH(launch_fwd, log_n, d, nd, a, subs, pb, st)
 }
-int dispatch_inv(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) {
-    NTT_DISPATCH(launch_inv, log_n, c, a, batch, st)
+int sub_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, hipStream_t st) {
+    NTT_DISPATCH(launch_inv, log_n, d, nd, a, subs, pb, st)
+}
+
+inline unsigned pass_grid(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
 }
 
 }  // namespace
 
 namespace fhe {
 
-int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return dispatch_fwd(c, a, log_n, batch, st); }
-int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return dispatch_inv(c, a, log_n, batch, st); }
+// rings above 2^14 do not fit one workgroup's LDS: one radix-2^pb pass over HBM + 2^pb sub-transforms of 2^14
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st) {
+    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, st);
+    const int pb = log_n - 14;
+    const size_t cols = batch << 14;
+    switch (pb) {
+        case 1: hipLaunchKernelGGL(ntt_big_fwd_pass<1>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        case 2: hipLaunchKernelGGL(ntt_big_fwd_pass<2>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        case 3: hipLaunchKernelGGL(ntt_big_fwd_pass<3>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        default: return FHE_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return sub_fwd(descs, n_desc, a, 14, batch << pb, pb, st);
+}
+
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st) {
+    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, st);
+    const int pb = log_n - 14;
+    int rc = sub_inv(descs, n_desc, a, 14, batch << pb, pb, st);
+    if (rc != FHE_OK) return rc;
+    const size_t cols = batch << 14;
+    switch (pb) {
+        case 1: hipLaunchKernelGGL(ntt_big_inv_pass<1>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        case 2: hipLaunchKernelGGL(ntt_big_inv_pass<2>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        case 3: hipLaunchKernelGGL(ntt_big_inv_pass<3>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+        default: return FHE_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
+}
+
+int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_fwd_multi(c->d_desc, 1, a, log_n, batch, st); }
+int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_inv_multi(c->d_desc, 1, a, log_n, batch, st); }
 
 int ctx_build_host(uint64_t q, fhe_ctx *c) {
     if (q < 3) return FHE_ERR_INVALID;
@@ -161,6 +196,13 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
         if (e == hipSuccess) e = hipMalloc(&c->d_twi, cap * sizeof(fhe::TwPair));
         if (e == hipSuccess) e = hipMemcpy(c->d_tw, pf.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->d_twi, pi.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
+        c->h_desc.q = q;
+        c->h_desc.tw = c->d_tw;
+        c->h_desc.twi = c->d_twi;
+        for (int k = 0; k < 20; ++k) { c->h_desc.ninv[k] = c->ninv[k]; c->h_desc.ninv_s[k] = c->ninv_s[k]; }
+        c->h_desc.one_s = fhe::shoup(1, q);
+        if (e == hipSuccess) e = hipMalloc(&c->d_desc, sizeof(fhe::ModDesc));
+        if (e == hipSuccess) e = hipMemcpy(c->d_desc, &c->h_desc, sizeof(fhe::ModDesc), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             g_last_hip = (int)e;
             fhe_ctx_destroy(c);
@@ -177,6 +219,7 @@ void fhe_ctx_destroy(fhe_ctx *c) {
         DeviceGuard guard(c->device);
         if (c->d_tw) (void)hipFree(c->d_tw);
         if (c->d_twi) (void)hipFree(c->d_twi);
+        if (c->d_desc) (void)hipFree(c->d_desc);
     }
     delete c;
 }
@@ -209,7 +252,7 @@ static int transform_entry(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t bat
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror m(a, n * batch, mem, true, st);
     if (m.rc != FHE_OK) return m.rc;
-    rc = inverse ? dispatch_inv(ctx, m.d, ilog2(n), batch, st) : dispatch_fwd(ctx, m.d, ilog2(n), batch, st);
+    rc = inverse ? fhe::ntt_inv_device(ctx, m.d, ilog2(n), batch, st) : fhe::ntt_fwd_device(ctx, m.d, ilog2(n), batch, st);
     if (rc != FHE_OK) return rc;
     return m.sync_out(st);
 }
@@ -264,10 +307,10 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
     HIP_TRY(hipMalloc((void **)&tb, count * sizeof(u64)));
     hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
-    if (rc == FHE_OK && n > 1) rc = dispatch_fwd(ctx, ma.d, log_n, batch, st);
-    if (rc == FHE_OK && n > 1) rc = dispatch_fwd(ctx, tb, log_n, batch, st);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, ma.d, log_n, batch, st);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, tb, log_n, batch, st);
     if (rc == FHE_OK) rc = launch_pointwise(ctx, ma.d, tb, count, st);
-    if (rc == FHE_OK && n > 1) rc = dispatch_inv(ctx, ma.d, log_n, batch, st);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_device(ctx, ma.d, log_n, batch, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // tb must outlive the launches
     (void)hipFree(tb);

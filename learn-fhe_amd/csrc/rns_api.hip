@@ -1,0 +1,290 @@
+// extern "C" entry points for SURVEY.md section 8(a) row a14: RNS base extension, rescale_k, CKKS key switch.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <set>
+#include <vector>
+
+#include "api_common.hpp"
+#include "ctx.hpp"
+#include "rns_kernels.hpp"
+
+struct fhe_rns_ctx {
+    int L = 0, K = 0, device = -1;
+    std::vector<uint64_t> qs, ps;
+    std::vector<fhe_ctx *> mods;       // L + K per-prime transform contexts (qs then ps)
+    fhe::ModDesc *d_descs = nullptr;   // [L + K]
+    fhe::Barrett *d_barrett = nullptr; // [L + K]
+    void *d_blob = nullptr;            // all conversion tables
+    fhe::BaseConv q2p{}, p2q{};
+    fhe::RescaleConsts resc{};
+    int max_log_n = 0;                 // largest ring degree every prime supports
+};
+
+struct fhe_ckks_key {
+    const fhe_rns_ctx *rns = nullptr;
+    int log_n = 0;
+    u64 *d_kb = nullptr, *d_ka = nullptr;  // [L + K][n], evaluation domain
+};
+
+namespace {
+
+using fhe::mulmod;
+
+uint64_t prod_mod(const std::vector<uint64_t> &xs, int skip, uint64_t m) {
+    uint64_t r = 1 % m;
+    for (int i = 0; i < (int)xs.size(); ++i)
+        if (i != skip) r = mulmod(r, xs[i] % m, m);
+    return r;
+}
+
+// lays the tables of one conversion A -> B into `blob` (host image), returns the device-pointer view
+struct BlobBuilder {
+    std::vector<uint64_t> words;  // doubles are bit-cast into words
+    size_t put(const std::vector<uint64_t> &v) {
+        size_t off = words.size();
+        words.insert(words.end(), v.begin(), v.end());
+        return off;
+    }
+    size_t put_f64(const std::vector<double> &v) {
+        size_t off = words.size();
+        for (double d : v) { uint64_t w; std::memcpy(&w, &d, 8); words.push_back(w); }
+        return off;
+    }
+};
+
+struct ConvOffsets { size_t a_mod, ahat_inv, ahat_inv_s, frac, b_mod, c, c_s, ua; int la, lb; };
+
+ConvOffsets build_conv(BlobBuilder &bb, const std::vector<uint64_t> &A, const std::vector<uint64_t> &B) {
+    const int la = (int)A.size(), lb = (int)B.size();
+    std::vector<uint64_t> inv(la), inv_s(la), c(size_t(lb) * la), c_s(size_t(lb) * la), ua(size_t(lb) * (la + 1));
+    std::vector<double> frac(la);
+    for (int i = 0; i < la; ++i) {
+        inv[i] = fhe::invmod(prod_mod(A, i, A[i]), A[i]);  // rns.rs:290-293
+        inv_s[i] = fhe::shoup(inv[i], A[i]);
+        frac[i] = 1.0 / (double)A[i];                      // rns.rs:294
+    }
+    for (int j = 0; j < lb; ++j) {
+        for (int i = 0; i < la; ++i) {
+            c[size_t(j) * la + i] = prod_mod(A, i, B[j]);  // rns.rs:305-313
+            c_s[size_t(j) * la + i] = fhe::shoup(c[size_t(j) * la + i], B[j]);
+        }
+        const uint64_t amod = prod_mod(A, -1, B[j]);
+        for (int u = 0; u <= la; ++u) ua[size_t(j) * (la + 1) + u] = mulmod(amod, (uint64_t)u % B[j], B[j]);  // rns.rs:315-320
+    }
+    ConvOffsets o;
+    o.la = la; o.lb = lb;
+    o.a_mod = bb.put(A); o.ahat_inv = bb.put(inv); o.ahat_inv_s = bb.put(inv_s); o.frac = bb.put_f64(frac);
+    o.b_mod = bb.put(B); o.c = bb.put(c); o.c_s = bb.put(c_s); o.ua = bb.put(ua);
+    return o;
+}
+
+fhe::BaseConv conv_view(const ConvOffsets &o, const uint64_t *base) {
+    fhe::BaseConv C;
+    C.la = o.la; C.lb = o.lb;
+    C.a_mod = (const u64 *)base + o.a_mod; C.ahat_inv = (const u64 *)base + o.ahat_inv; C.ahat_inv_s = (const u64 *)base + o.ahat_inv_s;
+    C.frac = (const double *)(base + o.frac);
+    C.b_mod = (const u64 *)base + o.b_mod; C.c = (const u64 *)base + o.c; C.c_s = (const u64 *)base + o.c_s; C.ua = (const u64 *)base + o.ua;
+    return C;
+}
+
+inline unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
+}
+
+}  // namespace
+
+extern "C" {
+
+void fhe_rns_ctx_destroy(fhe_rns_ctx *r) {
+    if (!r) return;
+    if (r->device >= 0) {
+        DeviceGuard guard(r->device);
+        if (r->d_descs) (void)hipFree(r->d_descs);
+        if (r->d_barrett) (void)hipFree(r->d_barrett);
+        if (r->d_blob) (void)hipFree(r->d_blob);
+    }
+    for (fhe_ctx *c : r->mods) fhe_ctx_destroy(c);
+    delete r;
+}
+
+int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int device, fhe_rns_ctx **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!qs || !ps || L < 1 || K < 1 || L > fhe::RNS_MAX_LIMBS || K > fhe::RNS_MAX_LIMBS) return FHE_ERR_INVALID;
+    std::set<uint64_t> uniq(qs, qs + L);
+    uniq.insert(ps, ps + K);
+    if ((int)uniq.size() != L + K) return FHE_ERR_INVALID;  // `assert!(... all_unique())`, rns.rs:25, 84
+    fhe_rns_ctx *r = new (std::nothrow) fhe_rns_ctx();
+    if (!r) return FHE_ERR_INVALID;
+    r->L = L; r->K = K; r->device = device;
+    r->qs.assign(qs, qs + L);
+    r->ps.assign(ps, ps + K);
+    r->max_log_n = 64;
+    for (int i = 0; i < L + K; ++i) {
+        fhe_ctx *c = nullptr;
+        int rc = fhe_ctx_create(i < L ? qs[i] : ps[i - L], device, &c);
+        if (rc != FHE_OK) { fhe_rns_ctx_destroy(r); return rc; }
+        r->mods.push_back(c);
+        if (c->log_cap < r->max_log_n) r->max_log_n = c->log_cap;
+    }
+    if (device < 0) { *out = r; return FHE_OK; }
+    DeviceGuard guard(device);
+    if (!guard.ok) { fhe_rns_ctx_destroy(r); return FHE_ERR_HIP; }
+    // tables
+    BlobBuilder bb;
+    ConvOffsets oq2p = build_conv(bb, r->qs, r->ps), op2q = build_conv(bb, r->ps, r->qs);
+    std::vector<uint64_t> half_q(L), half_p(K), pinv(L), pinv_s(L), red_mu(L);
+    auto half_of_p = [&](uint64_t m) {  // floor(P/2) mod m = (P mod m - 1) * 2^-1 mod m   (P odd, m odd)
+        return mulmod(fhe::submod(prod_mod(r->ps, -1, m), 1 % m, m), ((m + 1) / 2) % m, m);
+    };
+    for (int i = 0; i < L; ++i) {
+        half_q[i] = half_of_p(qs[i]);
+        pinv[i] = fhe::invmod(prod_mod(r->ps, -1, qs[i]), qs[i]);
+        pinv_s[i] = fhe::shoup(pinv[i], qs[i]);
+        red_mu[i] = (uint64_t)((((fhe::u128)1) << 64) / qs[i]);
+    }
+    for (int j = 0; j < K; ++j) half_p[j] = half_of_p(ps[j]);
+    const size_t o_hq = bb.put(half_q), o_hp = bb.put(half_p), o_pi = bb.put(pinv), o_pis = bb.put(pinv_s), o_mu = bb.put(red_mu);
+    std::vector<fhe::ModDesc> descs(L + K);
+    std::vector<fhe::Barrett> bar(L + K);
+    for (int i = 0; i < L + K; ++i) { descs[i] = r->mods[i]->h_desc; bar[i] = r->mods[i]->barrett; }
+    hipError_t e = hipMalloc(&r->d_blob, bb.words.size() * 8);
+    if (e == hipSuccess) e = hipMemcpy(r->d_blob, bb.words.data(), bb.words.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_descs, descs.size() * sizeof(fhe::ModDesc));
+    if (e == hipSuccess) e = hipMemcpy(r->d_descs, descs.data(), descs.size() * sizeof(fhe::ModDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->d_barrett, bar.size() * sizeof(fhe::Barrett));
+    if (e == hipSuccess) e = hipMemcpy(r->d_barrett, bar.data(), bar.size() * sizeof(fhe::Barrett), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { g_last_hip = (int)e; fhe_rns_ctx_destroy(r); return FHE_ERR_HIP; }
+    const uint64_t *base = (const uint64_t *)r->d_blob;
+    r->q2p = conv_view(oq2p, base);
+    r->p2q = conv_view(op2q, base);
+    r->resc.L = L; r->resc.K = K;
+    r->resc.q_mod = r->q2p.a_mod; r->resc.p_mod = r->q2p.b_mod;
+    r->resc.half_q = (const u64 *)base + o_hq; r->resc.half_p = (const u64 *)base + o_hp;
+    r->resc.pinv = (const u64 *)base + o_pi; r->resc.pinv_s = (const u64 *)base + o_pis;
+    r->resc.red_mu = (const u64 *)base + o_mu;
+    r->resc.p2q = r->p2q;
+    *out = r;
+    return FHE_OK;
+}
+
+int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror mi(in, n * batch * r->L, mem, true, st), mo(out, n * batch * r->K, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rns_extend_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n,
+                       batch, r->q2p);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t lk = size_t(r->L + r->K);
+    Mirror mi(in, n * batch * lk, mem, true, st), mo(out, n * batch * r->L, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, lk * n, mo.d, size_t(r->L) * n,
+                       (const u64 *)nullptr, size_t(0), n, batch, r->resc);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+void fhe_ckks_key_destroy(fhe_ckks_key *k) {
+    if (!k) return;
+    if (k->rns && k->rns->device >= 0) {
+        DeviceGuard guard(k->rns->device);
+        if (k->d_kb) (void)hipFree(k->d_kb);
+    }
+    delete k;
+}
+
+int fhe_ckks_ksk_prepare(const fhe_rns_ctx *r, const uint64_t *ksk_b, const uint64_t *ksk_a, size_t n, fhe_mem mem, fhe_ckks_key **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!r || !ksk_b || !ksk_a || !is_pow2(n)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    const int log_n = ilog2(n);
+    for (const fhe_ctx *c : r->mods)
+        if (log_n > c->s - 1) return FHE_ERR_NO_ROOT;
+    if (log_n > r->max_log_n) return FHE_ERR_UNSUPPORTED;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t lk = size_t(r->L + r->K), words = lk * n;
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 2 * words * sizeof(u64)));
+    hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipError_t e = hipMemcpy(d, ksk_b, words * sizeof(u64), kind);
+    if (e == hipSuccess) e = hipMemcpy(d + words, ksk_a, words * sizeof(u64), kind);
+    int rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    // both halves at once: polynomial p of the 2*lk uses descs[p % lk]
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, d, log_n, 2 * lk, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    if (rc != FHE_OK) { (void)hipFree(d); return rc; }
+    fhe_ckks_key *k = new (std::nothrow) fhe_ckks_key();
+    if (!k) { (void)hipFree(d); return FHE_ERR_INVALID; }
+    k->rns = r; k->log_n = log_n; k->d_kb = d; k->d_ka = d + words;
+    *out = k;
+    return FHE_OK;
+}
+
+// scheme/ckks/src/ckks.rs:284-293 for `batch` ciphertexts sharing one key: ct_b, ct_a [batch][L][n], in place
+int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch, fhe_mem mem,
+                        void *stream) {
+    if (!r || !key || key->rns != r || ((!ct_b || !ct_a) && batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int log_n = key->log_n;
+    const size_t n = size_t(1) << log_n, L = r->L, lk = size_t(r->L + r->K);
+    Mirror mb(ct_b, batch * L * n, mem, true, st), ma(ct_a, batch * L * n, mem, true, st);
+    if (mb.rc | ma.rc) return FHE_ERR_HIP;
+    u64 *ws = nullptr;  // ext | pb | pa, each [batch][lk][n]
+    const size_t blk = batch * lk * n;
+    HIP_TRY(hipMalloc((void **)&ws, 3 * blk * sizeof(u64)));
+    u64 *ext = ws, *pb = ws + blk, *pa = ws + 2 * blk;
+    int rc = FHE_OK;
+    // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps)
+    if (hipMemcpy2DAsync(ext, lk * n * 8, ma.d, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::rns_extend_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, L * n, ext + L * n, lk * n, n,
+                           batch, r->q2p);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, dim3(grid_for(blk)), dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
+                           (const u64 *)key->d_ka, pb, pa, n, (int)lk, batch, (const fhe::Barrett *)r->d_barrett);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    // pb and pa are adjacent: one inverse launch over 2 * batch * lk polynomials
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)pb, lk * n, mb.d, L * n,
+                           (const u64 *)mb.d, L * n, n, batch, r->resc);
+        hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)pa, lk * n, ma.d, L * n,
+                           (const u64 *)nullptr, size_t(0), n, batch, r->resc);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // workspace lifetime
+    (void)hipFree(ws);
+    return rc;
+}
+
+}  // extern "C"

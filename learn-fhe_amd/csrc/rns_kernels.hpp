@@ -1,0 +1,111 @@
+// RNS kernels: fast base conversion with the reference's f64 correction
+// (util/src/ring/rns.rs:331-345), rescale_k (rns.rs:103-132) and the limb-wise products of
+// Ckks::key_switch (scheme/ckks/src/ckks.rs:284-293).  One thread per coefficient; limb-major polynomials.
+#pragma once
+#include "dev_arith.hpp"
+
+namespace fhe {
+
+constexpr int RNS_MAX_LIMBS = 32;
+
+// conversion from base A (la moduli) to base B (lb moduli); all tables in HBM
+struct BaseConv {
+    int la, lb;
+    const u64 *a_mod;       // [la]
+    const u64 *ahat_inv;    // [la]  (A / a_i)^-1 mod a_i          (rns.rs:290-293 q_hats_inv_qs)
+    const u64 *ahat_inv_s;  // [la]  Shoup companions
+    const double *frac;     // [la]  1.0 / a_i as f64               (rns.rs:294 q_fracs)
+    const u64 *b_mod;       // [lb]
+    const u64 *c;           // [lb][la]  (A / a_i) mod b_j          (rns.rs:305-313 q_hats_ps)
+    const u64 *c_s;         // [lb][la]  Shoup companions
+    const u64 *ua;          // [lb][la + 1]  (u * A) mod b_j         (rns.rs:315-320 uq_ps)
+};
+
+// vs_i = v_i * ahat_inv_i mod a_i; u = round(sum_i frac_i * vs_i) with the reference's sequential f64 sum
+__device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 *v, u64 *vs) {
+    double acc = 0.0;
+    for (int i = 0; i < C.la; ++i) {
+        const u64 a = C.a_mod[i];
+        vs[i] = csub(mul_shoup_lazy(v[i], C.ahat_inv[i], C.ahat_inv_s[i], a), a);
+        acc = __dadd_rn(acc, __dmul_rn(C.frac[i], (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
+    }
+    return (int)round(acc);  // f64::round: half away from zero
+}
+
+// sum_i c_ji * vs_i - ua_j[u]  (mod b_j), canonical
+__device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 *vs, int u) {
+    const u64 b = C.b_mod[j], b2 = 2 * b;
+    u64 dot = 0;
+    for (int i = 0; i < C.la; ++i) dot = csub(dot + mul_shoup_lazy(vs[i], C.c[j * C.la + i], C.c_s[j * C.la + i], b), b2);
+    dot = csub(dot, b);
+    const u64 sub = C.ua[j * (C.la + 1) + u];
+    return dot >= sub ? dot - sub : dot + b - sub;
+}
+
+// util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
+__global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
+                                  BaseConv C) {
+    const size_t total = n * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        u64 v[RNS_MAX_LIMBS], vs[RNS_MAX_LIMBS];
+        for (int l = 0; l < C.la; ++l) v[l] = in[p * in_bs + size_t(l) * n + i];
+        const int u = base_conv_prepare(C, v, vs);
+        for (int j = 0; j < C.lb; ++j) out[p * out_bs + size_t(j) * n + i] = base_conv_out(C, j, vs, u);
+    }
+}
+
+struct RescaleConsts {
+    int L, K;
+    const u64 *q_mod, *p_mod;          // [L], [K]
+    const u64 *half_q, *half_p;        // floor(P/2) mod q_i, mod p_j        (rns.rs:120-125 `round`)
+    const u64 *pinv, *pinv_s;          // P^-1 mod q_i + Shoup               (rns.rs:127-132 `div`)
+    const u64 *red_mu;                 // [L] floor(2^64 / q_i): 64-bit Barrett for `vp % q_i` in the K == 1 path
+    BaseConv p2q;                      // switch_bases P -> Q                (rns.rs:93-97)
+};
+
+// util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
+// `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
+__global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
+                                   const u64 *addend, size_t add_bs, size_t n, size_t batch, RescaleConsts R) {
+    const size_t total = n * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        u64 vp[RNS_MAX_LIMBS], vs[RNS_MAX_LIMBS];
+        for (int j = 0; j < R.K; ++j) vp[j] = csub(in[p * in_bs + size_t(R.L + j) * n + i] + R.half_p[j], R.p_mod[j]);
+        int u = 0;
+        if (R.K > 1) u = base_conv_prepare(R.p2q, vp, vs);
+        for (int l = 0; l < R.L; ++l) {
+            const u64 q = R.q_mod[l];
+            const u64 vq = csub(in[p * in_bs + size_t(l) * n + i] + R.half_q[l], q);
+            u64 sw;
+            if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
+                const u64 x = vp[0];
+                sw = x - __umul64hi(x, R.red_mu[l]) * q;
+                sw = csub(csub(sw, q), q);
+            } else {
+                sw = base_conv_out(R.p2q, l, vs, u);
+            }
+            const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
+            u64 r = csub(mul_shoup_lazy(diff, R.pinv[l], R.pinv_s[l], q), q);
+            if (addend) r = csub(r + addend[p * add_bs + size_t(l) * n + i], q);
+            out[p * out_bs + size_t(l) * n + i] = r;
+        }
+    }
+}
+
+// ob = kb (.) e, oa = ka (.) e limb-wise in the evaluation domain; e, ob, oa: [batch][lk][n]; kb, ka: [lk][n]
+__global__ void rns_pointwise2_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
+                                      u64 *__restrict__ ob, u64 *__restrict__ oa, size_t n, int lk, size_t batch,
+                                      const Barrett *__restrict__ B) {
+    const size_t per = n * size_t(lk), total = per * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t within = idx % per;
+        const Barrett b = B[within / n];
+        const u64 x = e[idx];
+        ob[idx] = mulmod_barrett(x, kb[within], b);
+        oa[idx] = mulmod_barrett(x, ka[within], b);
+    }
+}
+
+}  // namespace fhe

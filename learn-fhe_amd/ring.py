@@ -196,3 +196,67 @@ class BootstrapKey:
             sched = [[("ak" if int(o) >> 31 else "ep", int(o) & 0x7FFFFFFF) for o in ops[i, :nops[i]]] for i in range(batch)]
             return out_a, out_b, sched
         return out_a, out_b
+
+
+# ---- row a14: RNS rings / CKKS key switch ----------------------------------------------------------------
+
+
+class RnsContext:
+    """util/src/ring/rns.rs `Rns` for bases qs (L) and ps (K)."""
+
+    def __init__(self, qs, ps, device=0):
+        self.qs, self.ps, self.L, self.K = list(qs), list(ps), len(qs), len(ps)
+        a, b = (C.c_uint64 * self.L)(*qs), (C.c_uint64 * self.K)(*ps)
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_rns_ctx_create(a, self.L, b, self.K, device, C.byref(self._h)), "fhe_rns_ctx_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_rns_ctx_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def extend_bases(self, limbs, n):
+        """rns.rs:83-91: [batch][L][n] -> the K new limbs [batch][K][n]."""
+        p, cnt, mem, st = _buf(limbs)
+        batch = cnt // (self.L * n)
+        out = _like(limbs, (batch, self.K, n))
+        po, _, _, _ = _buf(out)
+        L.check(L.lib().fhe_rns_extend_bases(self._h, p, po, n, batch, mem, st), "fhe_rns_extend_bases")
+        return out
+
+    def rescale_k(self, limbs, n):
+        """rns.rs:103-118: [batch][L+K][n] -> [batch][L][n]."""
+        p, cnt, mem, st = _buf(limbs)
+        batch = cnt // ((self.L + self.K) * n)
+        out = _like(limbs, (batch, self.L, n))
+        po, _, _, _ = _buf(out)
+        L.check(L.lib().fhe_rns_rescale_k(self._h, p, po, n, batch, mem, st), "fhe_rns_rescale_k")
+        return out
+
+
+class CkksKey:
+    """A CKKS key-switching key (scheme/ckks/src/ckks.rs:86-88) prepared in the evaluation domain."""
+
+    def __init__(self, rns: RnsContext, ksk_b, ksk_a, n):
+        self.rns, self.n = rns, n
+        pb, cnt, mem, _ = _buf(ksk_b)
+        pa, cnta, mema, _ = _buf(ksk_a)
+        assert cnt == cnta == (rns.L + rns.K) * n and mem == mema
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_ckks_ksk_prepare(rns.handle, pb, pa, n, mem, C.byref(self._h)), "fhe_ckks_ksk_prepare")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_ckks_key_destroy(h)
+
+    def key_switch_(self, ct_b, ct_a):
+        """scheme/ckks/src/ckks.rs:284-293, in place on [batch][L][n] b/a."""
+        pb, cnt, mem, st = _buf(ct_b)
+        pa, _, _, _ = _buf(ct_a)
+        batch = cnt // (self.rns.L * self.n)
+        L.check(L.lib().fhe_ckks_key_switch(self.rns.handle, self._h, pb, pa, batch, mem, st), "fhe_ckks_key_switch")

@@ -120,7 +120,7 @@ typedef struct {
     u64 *tw, *twi;
 } ref_twiddle;
 
-#define MAX_TW 64
+#define MAX_TW 4096
 static ref_twiddle g_tw[MAX_TW];
 static int g_ntw = 0;
 
