@@ -21,6 +21,9 @@ struct fhe_ctx {
     fhe::Barrett barrett{};
     int device = -1;
     fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM
+    u64 *d_tww = nullptr, *d_twwi = nullptr;        // plain twiddles for the pseudo-Mersenne path (null if not eligible)
+    int pm_b = 0;                                   // q = 2^pm_b - pm_c, or 0
+    unsigned pm_c = 0;
     fhe::ModDesc *d_desc = nullptr;                 // this modulus as the kernels read it (1 entry)
     fhe::ModDesc h_desc{};
 };
@@ -29,6 +32,8 @@ namespace fhe {
 constexpr int MAX_LOG_N = 17;
 int ctx_build_host(uint64_t q, fhe_ctx *c);  // returns FHE_* status
 // batched transforms over `batch` polynomials of degree 2^log_n; polynomial p uses descs[p % n_desc]
-int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st);
-int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st);
+// pm: common bit length b if EVERY descriptor is pseudo-Mersenne eligible with the same b (the N = 2^14 kernels then use
+// ArithPM<b> when instantiated), else 0
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0);
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0);
 }  // namespace fhe

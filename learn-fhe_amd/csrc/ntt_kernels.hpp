@@ -50,7 +50,16 @@ struct ModDesc {
     const TwPair *tw, *twi;
     u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
     u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
+    // pseudo-Mersenne fast path (ntt14.hpp): q = 2^pm_b - pm_c, plain twiddle tables (no companions); pm_b = 0: not eligible
+    const u64 *tww, *twwi;
+    unsigned pm_c;
+    int pm_b;
 };
+
+// DIRECT (template flag of the transform kernels): the pass that owns 2^LOG_E contiguous coefficients per thread
+// (last forward pass, first inverse pass) moves them between registers and HBM itself with 16-byte accesses
+// (each thread owns whole 128-byte lines) instead of staging the polynomial through LDS once more.  Measured on
+// MI355X (tools/ntt_lab.hip): a win for the inverse's loads, a loss for the forward's stores.
 
 // Developer-lab ablation hooks (tools/ntt_lab.hip); never defined in the product build.
 #ifdef FHE_ABLATE_NO_GLOBAL
@@ -131,7 +140,7 @@ __device__ __forceinline__ void exchange_sync() {
 // x[gg*2^R0 + r]) and gets the evaluations back in x[] in the last pass's layout (coefficient t*E + r at
 // x[r]), still lazy in [0, 4q); nothing touches global memory.
 // ---------------------------------------------------------------------------------------------
-template <typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false>
+template <typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>
 __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
                                         const TwSel tw, u64 q, u64 q2) {
     constexpr int E = 1 << LOG_E;
@@ -169,6 +178,23 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r)
                 if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), canon4(x[gg * (1 << R) + r], q, q2));
+    } else if constexpr (last && DIRECT) {
+        // h == 0: register r holds coefficient (t << LOG_E) + r
+        static_assert(G == 1, "last pass is a full pass");
+        if (active) {
+            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(g + (size_t(t) << LOG_E));
+#pragma unroll
+            for (int r = 0; r < E; r += 2) {
+                ulonglong2 v;
+                v.x = canon4(x[r], q, q2);
+                v.y = canon4(x[r + 1], q, q2);
+#ifdef FHE_ABLATE_NO_GLOBAL
+                if (v.x == 0xdeadbeefcafef00dull) dst[r >> 1] = v;
+#else
+                dst[r >> 1] = v;
+#endif
+            }
+        }
     } else {
 #pragma unroll
         for (int gg = 0; gg < G; ++gg)
@@ -179,15 +205,16 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = v;
             }
         exchange_sync<WAVE>();
-        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R, REGS_IO, WAVE>(x, t, g, lds, active, tw, q, q2);
+        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, tw, q, q2);
     }
 }
 
 // data: `subs` sub-polynomials of size 2^LOG_N, contiguous; sub s belongs to polynomial s >> pb (modulus descriptor
 // (s >> pb) % n_desc) and is its sub-transform number s & (2^pb - 1).  pb = 0: plain transforms.
-template <int LOG_N, int LOG_E, int PPW>
+template <int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = false>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_kernel(
-    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
+    const int pb = PFX ? pb_arg : 0;  // PFX = false: every twiddle index folds to a constant expression
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
@@ -200,8 +227,8 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
     const u64 q2 = 2 * q;
-    fwd_run<C, LOG_N, LOG_E, 0>(x, t, g, lds, active, tw, q, q2);
-    if constexpr (C::P > 1) {
+    fwd_run<C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, tw, q, q2);
+    if constexpr (C::P > 1 && !DIRECT) {
         // the canonical image sits in LDS: stream it out with consecutive lanes on consecutive addresses
         if (active) {
 #pragma unroll
@@ -218,7 +245,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 // ---------------------------------------------------------------------------------------------
 // REGS_IO: x[] comes in in the last-layer pass layout (coefficient t*E + r at x[r], values in [0, 2q)) and
 // leaves in the first-pass layout, multiplied by n^-1 and canonical.
-template <typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false>  // layers [L0, LEND)
+template <typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>  // layers [L0, LEND)
 __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
                                         const TwSel twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
     constexpr int E = 1 << LOG_E;
@@ -234,6 +261,15 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             const int i = pass_index<LOG_N, L0, R>(grp, r);
             if constexpr (REGS_IO && LEND == LOG_N) {
                 (void)i;
+            } else if constexpr (DIRECT && LEND == LOG_N && C::P > 1) {
+                if ((r & 1) == 0) {
+#ifdef FHE_ABLATE_NO_GLOBAL
+                    x[r] = gload(g, i); x[r + 1] = gload(g, i + 1);
+#else
+                    const ulonglong2 v = active ? *reinterpret_cast<const ulonglong2 *>(g + i) : ulonglong2{0, 0};
+                    x[r] = v.x; x[r + 1] = v.y;
+#endif
+                }
             } else if constexpr (C::P == 1) {
                 x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
             } else {
@@ -265,13 +301,14 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             for (int r = 0; r < (1 << R); ++r)
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = x[gg * (1 << R) + r];
         exchange_sync<WAVE>();
-        inv_run<C, LOG_N, LOG_E, L0, REGS_IO, WAVE>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+        inv_run<C, LOG_N, LOG_E, L0, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
     }
 }
 
-template <int LOG_N, int LOG_E, int PPW>
+template <int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = true>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_kernel(
-    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
+    const int pb = PFX ? pb_arg : 0;
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x % C::T, pw = threadIdx.x / C::T;
@@ -286,7 +323,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
     const u64 q2 = 2 * q;
-    if constexpr (C::P > 1) {
+    if constexpr (C::P > 1 && !DIRECT) {
 #pragma unroll
         for (int k = 0; k < C::E; ++k) {
             const int i = t + C::T * k;
@@ -294,7 +331,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
         }
         __syncthreads();
     }
-    inv_run<C, LOG_N, LOG_E, LOG_N>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+    inv_run<C, LOG_N, LOG_E, LOG_N, false, false, DIRECT>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
 }
 
 // Opening radix-2^PB pass of a ring of degree 2^log_n (layers 0..PB-1 across the 2^PB blocks), one thread per

@@ -8,6 +8,7 @@
 #include "api_common.hpp"
 #include "ctx.hpp"
 #include "ntt_kernels.hpp"
+#include "ntt14.hpp"
 
 using fhe::u64;
 
@@ -22,10 +23,10 @@ int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
     return FHE_OK;
 }
 
-template <int LOG_N, int LOG_E, int PPW>
+template <int LOG_N, int LOG_E, int PPW, bool PFX = false>
 int launch_fwd(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
-    auto k = fhe::ntt_fwd_kernel<LOG_N, LOG_E, PPW>;
+    auto k = fhe::ntt_fwd_kernel<LOG_N, LOG_E, PPW, PFX, false>;
     if (C::LDS_BYTES > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
@@ -34,10 +35,10 @@ int launch_fwd(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, 
     return FHE_OK;
 }
 
-template <int LOG_N, int LOG_E, int PPW>
+template <int LOG_N, int LOG_E, int PPW, bool PFX = false>
 int launch_inv(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
-    auto k = fhe::ntt_inv_kernel<LOG_N, LOG_E, PPW>;
+    auto k = fhe::ntt_inv_kernel<LOG_N, LOG_E, PPW, PFX, true>;
     if (C::LDS_BYTES > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
@@ -63,15 +64,38 @@ int launch_inv(const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, 
         case 11: return FN<11, 4, 2>(__VA_ARGS__);            \
         case 12: return FN<12, 4, 1>(__VA_ARGS__);            \
         case 13: return FN<13, 4, 1>(__VA_ARGS__);            \
-        case 14: return FN<14, 4, 1>(__VA_ARGS__);            \
         default: return FHE_ERR_UNSUPPORTED;                  \
     }
 
-int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, hipStream_t st) {
-    NTT_DISPATCH(launch_fwd, log_n, d, nd, a, subs, pb, st)
+// N = 2^14 (and the sub-transforms of larger rings): the register-resident kernels of ntt14.hpp
+template <class A>
+int launch14(bool inverse, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
+    auto k = inverse ? fhe::ntt14_inv_kernel<A> : fhe::ntt14_fwd_kernel<A>;
+    HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fhe::N14_LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::N14_THREADS), fhe::N14_LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
 }
-int sub_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, hipStream_t st) {
-    NTT_DISPATCH(launch_inv, log_n, d, nd, a, subs, pb, st)
+
+// pm = common bit length of pseudo-Mersenne eligible moduli for which a kernel is instantiated (60, 54), else 0
+int launch14_any(bool inverse, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, int pm, hipStream_t st) {
+    if (pm == 60) return launch14<fhe::ArithPM<60>>(inverse, d, nd, a, subs, pb, st);
+    if (pm == 54) return launch14<fhe::ArithPM<54>>(inverse, d, nd, a, subs, pb, st);
+    // other primes: measured on MI355X (tools/ntt_lab.hip), the LDS-resident kernel is the faster forward transform and
+    // the register-resident one the faster inverse
+    if (!inverse) return pb ? launch_fwd<14, 4, 1, true>(d, nd, a, subs, pb, st) : launch_fwd<14, 4, 1, false>(d, nd, a, subs, 0, st);
+    return launch14<fhe::ArithShoup>(true, d, nd, a, subs, pb, st);
+}
+
+int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
+    if (log_n == 14) return launch14_any(false, d, nd, a, subs, pb, pm, st);
+    if (pb) return FHE_ERR_UNSUPPORTED;
+    NTT_DISPATCH(launch_fwd, log_n, d, nd, a, subs, 0, st)
+}
+int sub_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
+    if (log_n == 14) return launch14_any(true, d, nd, a, subs, pb, pm, st);
+    if (pb) return FHE_ERR_UNSUPPORTED;
+    NTT_DISPATCH(launch_inv, log_n, d, nd, a, subs, 0, st)
 }
 
 inline unsigned pass_grid(size_t total) {
@@ -84,8 +108,8 @@ inline unsigned pass_grid(size_t total) {
 namespace fhe {
 
 // rings above 2^14 do not fit one workgroup's LDS: one radix-2^pb pass over HBM + 2^pb sub-transforms of 2^14
-int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st) {
-    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, st);
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm) {
+    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st);
     const int pb = log_n - 14;
     const size_t cols = batch << 14;
     switch (pb) {
@@ -95,13 +119,13 @@ int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size
         default: return FHE_ERR_UNSUPPORTED;
     }
     HIP_TRY(hipGetLastError());
-    return sub_fwd(descs, n_desc, a, 14, batch << pb, pb, st);
+    return sub_fwd(descs, n_desc, a, 14, batch << pb, pb, pm, st);
 }
 
-int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st) {
-    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, st);
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm) {
+    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st);
     const int pb = log_n - 14;
-    int rc = sub_inv(descs, n_desc, a, 14, batch << pb, pb, st);
+    int rc = sub_inv(descs, n_desc, a, 14, batch << pb, pb, pm, st);
     if (rc != FHE_OK) return rc;
     const size_t cols = batch << 14;
     switch (pb) {
@@ -114,8 +138,8 @@ int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size
     return FHE_OK;
 }
 
-int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_fwd_multi(c->d_desc, 1, a, log_n, batch, st); }
-int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_inv_multi(c->d_desc, 1, a, log_n, batch, st); }
+int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_fwd_multi(c->d_desc, 1, a, log_n, batch, st, c->pm_b); }
+int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_inv_multi(c->d_desc, 1, a, log_n, batch, st, c->pm_b); }
 
 int ctx_build_host(uint64_t q, fhe_ctx *c) {
     if (q < 3) return FHE_ERR_INVALID;
@@ -148,6 +172,12 @@ int ctx_build_host(uint64_t q, fhe_ctx *c) {
         c->ninv_s[k] = shoup(c->ninv[k], q);
     }
     int nbits = 64 - __builtin_clzll(q);
+    // pseudo-Mersenne eligibility (ntt14.hpp): q = 2^b - c with 33 <= b <= 60 and c <= 2^(b-33)
+    c->pm_b = 0; c->pm_c = 0;
+    if (nbits >= 34 && nbits <= 60) {
+        const uint64_t cc = (uint64_t(1) << nbits) - q;
+        if (cc <= (uint64_t(1) << (nbits - 33))) { c->pm_b = nbits; c->pm_c = (unsigned)cc; }
+    }
     c->barrett.q = q;
     c->barrett.mu = (u64)((((u128)1) << (2 * nbits)) / q);
     c->barrett.sh1 = nbits - 1;
@@ -196,6 +226,28 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
         if (e == hipSuccess) e = hipMalloc(&c->d_twi, cap * sizeof(fhe::TwPair));
         if (e == hipSuccess) e = hipMemcpy(c->d_tw, pf.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->d_twi, pi.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
+        if (e == hipSuccess && c->pm_b) {
+            // twiddles in the 16-byte form ntt14.hpp's pm_mul reads: {wl, wl << (63-b), wh, 2 wh}, w = wl + wh 2^(b-31)
+            const int b = c->pm_b;
+            std::vector<fhe::PmTw> lf(cap), li(cap);
+            auto split = [b](uint64_t w) {
+                fhe::PmTw t;
+                t.wl = (unsigned)(w & ((uint64_t(1) << (b - 31)) - 1));
+                t.wlp = t.wl << (63 - b);
+                t.wh = (unsigned)(w >> (b - 31));
+                t.wh2 = t.wh << 1;
+                return t;
+            };
+            for (size_t j = 0; j < cap; ++j) { lf[j] = split(c->tw[j]); li[j] = split(c->twi[j]); }
+            e = hipMalloc((void **)&c->d_tww, 2 * cap * sizeof(fhe::PmTw));
+            c->d_twwi = c->d_tww + 2 * cap;  // u64 units: one PmTw = 2 words
+            if (e == hipSuccess) e = hipMemcpy(c->d_tww, lf.data(), cap * sizeof(fhe::PmTw), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->d_twwi, li.data(), cap * sizeof(fhe::PmTw), hipMemcpyHostToDevice);
+        }
+        c->h_desc.tww = c->d_tww;
+        c->h_desc.twwi = c->d_twwi;
+        c->h_desc.pm_b = c->pm_b;
+        c->h_desc.pm_c = c->pm_c;
         c->h_desc.q = q;
         c->h_desc.tw = c->d_tw;
         c->h_desc.twi = c->d_twi;
@@ -220,6 +272,7 @@ void fhe_ctx_destroy(fhe_ctx *c) {
         if (c->d_tw) (void)hipFree(c->d_tw);
         if (c->d_twi) (void)hipFree(c->d_twi);
         if (c->d_desc) (void)hipFree(c->d_desc);
+        if (c->d_tww) (void)hipFree(c->d_tww);
     }
     delete c;
 }

@@ -20,6 +20,7 @@ struct fhe_rns_ctx {
     fhe::BaseConv q2p{}, p2q{};
     fhe::RescaleConsts resc{};
     int max_log_n = 0;                 // largest ring degree every prime supports
+    int all_pm = -1;                   // common pseudo-Mersenne bit length of all primes, 0 if none
 };
 
 struct fhe_ckks_key {
@@ -129,6 +130,8 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
         if (rc != FHE_OK) { fhe_rns_ctx_destroy(r); return rc; }
         r->mods.push_back(c);
         if (c->log_cap < r->max_log_n) r->max_log_n = c->log_cap;
+        if (r->all_pm == -1) r->all_pm = c->pm_b;
+        else if (r->all_pm != c->pm_b) r->all_pm = 0;
     }
     if (device < 0) { *out = r; return FHE_OK; }
     DeviceGuard guard(device);
@@ -230,7 +233,7 @@ int fhe_ckks_ksk_prepare(const fhe_rns_ctx *r, const uint64_t *ksk_b, const uint
     if (e == hipSuccess) e = hipMemcpy(d + words, ksk_a, words * sizeof(u64), kind);
     int rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     // both halves at once: polynomial p of the 2*lk uses descs[p % lk]
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, d, log_n, 2 * lk, nullptr);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, d, log_n, 2 * lk, nullptr, r->all_pm);
     if (hipDeviceSynchronize() != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
     if (rc != FHE_OK) { (void)hipFree(d); return rc; }
     fhe_ckks_key *k = new (std::nothrow) fhe_ckks_key();
@@ -265,14 +268,14 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
                            batch, r->q2p);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, dim3(grid_for(blk)), dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
                            (const u64 *)key->d_ka, pb, pa, n, (int)lk, batch, (const fhe::Barrett *)r->d_barrett);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     // pb and pa are adjacent: one inverse launch over 2 * batch * lk polynomials
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st);
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st, r->all_pm);
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)pb, lk * n, mb.d, L * n,
                            (const u64 *)mb.d, L * n, n, batch, r->resc);

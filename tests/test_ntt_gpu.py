@@ -65,7 +65,8 @@ def test_golden_vectors(fhe, torch_cuda):
 def test_forward_inverse_vs_oracle(fhe, cref, torch_cuda, log_n):
     """every supported size, three moduli widths, ragged batch (not a multiple of the polynomials per workgroup)"""
     n = 1 << log_n
-    cases = [(45, 3), (30, 2), (60, 2)] if log_n <= 12 else [(60, 2), (54, 1)]
+    # 60-/54-bit primes of two_adic_primes are pseudo-Mersenne eligible (ntt14.hpp ArithPM), 45-/61-bit ones are not (Shoup)
+    cases = [(45, 3), (30, 2), (60, 2)] if log_n <= 12 else [(60, 2), (54, 1), (45, 1), (61, 1)]
     for bits, count in cases:
         if bits <= log_n + 1:
             continue
@@ -96,6 +97,28 @@ def test_ring_product_vs_schoolbook(fhe, cref, torch_cuda, log_n):
         da, db = to_dev(torch_cuda, a), to_dev(torch_cuda, b)
         ctx.mul_(da, db, n)
         assert np.array_equal(to_host(da), cref.schoolbook_mul(q, a, b))
+
+
+def test_extreme_values_2p14(fhe, cref, torch_cuda):
+    """lazy-reduction bounds: all-(q-1), all-zero and alternating extremes through both arithmetic policies"""
+    n = 1 << 14
+    for q in (1152921504606748673, cref.two_adic_primes(54, 15, 1)[0], cref.two_adic_primes(45, 15, 1)[0],
+              cref.two_adic_primes(61, 15, 1)[0]):
+        ctx = fhe.NttContext(q)
+        pats = np.zeros((4, n), dtype=np.uint64)
+        pats[0, :] = q - 1
+        pats[2, 0::2] = q - 1
+        pats[3, :] = q >> 1
+        d = to_dev(torch_cuda, pats)
+        ctx.ntt_(d, n)
+        assert np.array_equal(to_host(d).reshape(-1), cref.ntt_fwd(q, pats.reshape(-1), n, threads=4)), q
+        ctx.intt_(d, n)
+        assert np.array_equal(to_host(d), pats), q
+        ev = np.full((2, n), q - 1, dtype=np.uint64)  # inverse on extreme evaluations
+        ev[1, 1::2] = 0
+        d = to_dev(torch_cuda, ev)
+        ctx.intt_(d, n)
+        assert np.array_equal(to_host(d).reshape(-1), cref.ntt_inv(q, ev.reshape(-1), n, threads=4)), q
 
 
 def test_pointwise_mul(fhe, cref, torch_cuda):

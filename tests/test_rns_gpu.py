@@ -38,7 +38,7 @@ def host(t):
 def test_big_ring_transforms(fhe, cref, torch_cuda, log_n):
     """N = 2^15 (cfg4 ring), 2^16: forward == oracle, inverse(forward) == identity, ring product == oracle"""
     n = 1 << log_n
-    for q in cref.two_adic_primes(60, log_n + 1, 2):
+    for q in cref.two_adic_primes(60, log_n + 1, 2) + cref.two_adic_primes(45, log_n + 1, 1):  # pseudo-Mersenne and Shoup paths
         batch = 3
         rng = np.random.Generator(np.random.PCG64(log_n))
         a = rng.integers(0, q, size=(batch, n), dtype=np.uint64)

@@ -9,6 +9,24 @@ typedef unsigned int u32;
 #define ITERS 4096
 #define CHAINS 8
 
+// pseudo-Mersenne q = 2^B - c: w*y mod q (lazy) with 7 full 32x32->64 multiply-adds and no companion table
+template <int B>
+__device__ __forceinline__ u64 pm_mul(u64 y, u64 w, u32 c) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    const u64 m0 = (u64)w0 * y0;
+    const u64 m1 = (u64)w0 * y1 + (m0 >> 32);
+    const u64 m2 = (u64)w1 * y0 + (u32)m1;
+    const u64 m3 = (u64)w1 * y1 + ((m1 >> 32) + (m2 >> 32));
+    const u64 plo = ((u64)(u32)m2 << 32) | (u32)m0;
+    const u64 H = (m3 << (64 - B)) | (plo >> B);
+    const u64 L = plo & ((1ull << B) - 1);
+    const u64 s0 = (u64)(u32)H * c + L;
+    const u64 s1 = (u64)(u32)(H >> 32) * c + (s0 >> 32);
+    const u32 H2 = (u32)(s1 >> (B - 32));
+    const u64 L2 = ((s1 & ((1ull << (B - 32)) - 1)) << 32) | (u32)s0;
+    return (u64)H2 * c + L2;
+}
+
 template <int OP>
 __global__ void kern(u64 *out, u64 seed, u64 q) {
     u64 x[CHAINS];
@@ -31,6 +49,15 @@ __global__ void kern(u64 *out, u64 seed, u64 q) {
             if (OP == 6) { u64 hi = __umul64hi(ws, x[c]); x[c] = w * x[c] - hi * q; }  // Shoup lazy mul
             if (OP == 7) f[c] = __builtin_fma(f[c], 1.0000001, 0.5);            // v_fma_f64
             if (OP == 8) x[c] = x[c] + (x[c] >> 3);                              // 64-bit add + shift
+            if (OP == 10) x[c] = pm_mul<60>(x[c], w & ((1ull << 60) - 1), 98303u);
+            if (OP == 11) {
+                if ((c & 1) == 0) {
+                    u64 X = x[c], Y = x[c + 1];
+                    u64 tt = pm_mul<60>(Y, w & ((1ull << 60) - 1), 98303u);
+                    x[c] = X + tt; x[c + 1] = X - tt + 2 * q;
+                }
+            }
+            if (OP == 12) x[c] = (x[c] & ((1ull << 60) - 1)) + (u64)(u32)(x[c] >> 60) * 98303u;  // lazy fold
             if (OP == 9) {                                                        // full Harvey CT butterfly (pair c, c^1)
                 if ((c & 1) == 0) {
                     u64 X = x[c], Y = x[c + 1], q2 = 2 * q;
@@ -80,5 +107,8 @@ int main() {
     run<7>("v_fma_f64", 1);
     run<8>("add64 + shr64", 1);
     run<9>("Harvey CT butterfly", 0.5);
+    run<10>("PM (2^60-c) lazy modmul", 1);
+    run<11>("PM CT butterfly", 0.5);
+    run<12>("PM lazy fold", 1);
     return 0;
 }

@@ -5,7 +5,31 @@
 #include <vector>
 #include "../learn-fhe_amd/csrc/modmath.hpp"
 #include "../learn-fhe_amd/csrc/ntt_kernels.hpp"
+#include "../learn-fhe_amd/csrc/ntt14.hpp"
 using namespace fhe;
+// ablation policies for the ntt14 structure
+struct ArithNone : ArithPM<60> {  // exchanges + HBM traffic only
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int, const K &) { X ^= 1; Y ^= 1; }
+    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int, const K &) { X ^= 1; Y ^= 1; }
+    static constexpr bool GS_FOLDS = false;
+    static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 finish_inv(u64 x, const K &) { return x; }
+};
+struct ArithNoTw : ArithPM<60> {  // butterflies with a register-resident twiddle: no twiddle loads
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
+        PmTw w = k.ninv; w.wl += idx;
+        const u64 t = pm_mul<60>(Y, w, k.m);
+        const u64 x = X;
+        X = x + t; Y = x - t + k.m.q2;
+    }
+    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
+        PmTw w = k.ninv; w.wl += idx;
+        const u64 s = X + Y;
+        const u64 d = X - Y + (PH ? k.m.q4 : k.m.q2);
+        X = s; Y = pm_mul<60>(d, w, k.m);
+    }
+};
 #ifndef LAB_LOG_N
 #define LAB_LOG_N 14
 #endif
@@ -53,35 +77,100 @@ int main(int argc, char **argv) {
     hipMalloc(&d_tw, cap * sizeof(TwPair)); hipMalloc(&d_twi, cap * sizeof(TwPair));
     hipMemcpy(d_tw, tw.data(), cap * sizeof(TwPair), hipMemcpyHostToDevice);
     hipMemcpy(d_twi, twi.data(), cap * sizeof(TwPair), hipMemcpyHostToDevice);
+    ModDesc hd{};
+    hd.q = q; hd.tw = d_tw; hd.twi = d_twi; hd.one_s = shoup(1, q);
+    for (int k = 0; k < 20; ++k) { hd.ninv[k] = invmod((u64(1) << k) % q, q); hd.ninv_s[k] = shoup(hd.ninv[k], q); }
+    {   // pseudo-Mersenne tables (q = 2^60 - 98303)
+        std::vector<PmTw> w(cap), wi(cap);
+        for (size_t j = 0; j < cap; ++j) { w[j] = ArithPM<60>::split(tw[j].w); wi[j] = ArithPM<60>::split(twi[j].w); }
+        PmTw *dw, *dwi;
+        hipMalloc(&dw, cap * sizeof(PmTw)); hipMalloc(&dwi, cap * sizeof(PmTw));
+        hipMemcpy(dw, w.data(), cap * sizeof(PmTw), hipMemcpyHostToDevice);
+        hipMemcpy(dwi, wi.data(), cap * sizeof(PmTw), hipMemcpyHostToDevice);
+        hd.tww = (const u64 *)dw; hd.twwi = (const u64 *)dwi; hd.pm_b = 60; hd.pm_c = (unsigned)((u64(1) << 60) - q);
+    }
+    ModDesc *d_desc;
+    hipMalloc(&d_desc, sizeof(ModDesc));
+    hipMemcpy(d_desc, &hd, sizeof(ModDesc), hipMemcpyHostToDevice);
     std::vector<u64> h(size_t(n) * batch);
     u64 st = 88172645463325252ull;
     for (auto &v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = st % q; }
     hipMalloc(&d, h.size() * 8);
     hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     using C = NttCfg<LAB_LOG_N, 4, 1>;
-    auto kf = ntt_fwd_kernel<LAB_LOG_N, 4, 1>;
-    auto ki = ntt_inv_kernel<LAB_LOG_N, 4, 1>;
-    hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    hipFuncSetAttribute((const void *)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    u64 ninv = invmod((u64)n % q, q), ninv_s = shoup(ninv, q);
+    typedef void (*kern_t)(u64 *, const ModDesc *, unsigned, unsigned, int);
+    struct Variant { const char *name; kern_t f, i; };
+    struct V14 { const char *name; kern_t f, i; };
+    V14 v14[] = {
+        {"ntt14 Shoup (512 thr, 2 WG/CU)", ntt14_fwd_kernel<ArithShoup>, ntt14_inv_kernel<ArithShoup>},
+        {"ntt14 pseudo-Mersenne", ntt14_fwd_kernel<ArithPM<60>>, ntt14_inv_kernel<ArithPM<60>>},
+        {"ntt14 ablation: no butterflies", ntt14_fwd_kernel<ArithNone>, ntt14_inv_kernel<ArithNone>},
+        {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw>, ntt14_inv_kernel<ArithNoTw>},
+    };
+    Variant vars[] = {
+        {"fwd staged / inv direct (product)", ntt_fwd_kernel<LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<LAB_LOG_N, 4, 1, false, true>},
+        {"fwd direct / inv staged", ntt_fwd_kernel<LAB_LOG_N, 4, 1, false, true>, ntt_inv_kernel<LAB_LOG_N, 4, 1, false, false>},
+        {"runtime prefix (pb arg honoured)", ntt_fwd_kernel<LAB_LOG_N, 4, 1, true, false>, ntt_inv_kernel<LAB_LOG_N, 4, 1, true, true>},
+    };
+    const int nv = sizeof(vars) / sizeof(vars[0]);
+    for (auto &v : vars) {
+        hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        hipFuncSetAttribute((const void *)v.i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    }
     hipEvent_t e0, e1, e2;
     hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
-    float best_f = 1e9, best_i = 1e9, sum_f = 0, sum_i = 0;
-    const int reps = 12;
-    for (int r = 0; r < reps + 2; ++r) {
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(kf, dim3(batch), dim3(C::THREADS), C::LDS_BYTES, 0, d, d_tw, q, (unsigned)batch);
-        hipEventRecord(e1);
-        hipLaunchKernelGGL(ki, dim3(batch), dim3(C::THREADS), C::LDS_BYTES, 0, d, d_twi, q, (unsigned)batch, ninv, ninv_s);
-        hipEventRecord(e2);
-        hipEventSynchronize(e2);
-        float f, i;
-        hipEventElapsedTime(&f, e0, e1); hipEventElapsedTime(&i, e1, e2);
-        if (r >= 2) { best_f = f < best_f ? f : best_f; best_i = i < best_i ? i : best_i; sum_f += f; sum_i += i; }
-    }
+    const int reps = 10;
+    std::vector<float> sf(nv, 0), si(nv, 0), bf(nv, 1e9f), bi(nv, 1e9f);
+    for (int r = 0; r < reps + 2; ++r)
+        for (int k = 0; k < nv; ++k) {  // interleaved rounds in one process
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(vars[k].f, dim3(batch), dim3(C::THREADS), C::LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipEventRecord(e1);
+            hipLaunchKernelGGL(vars[k].i, dim3(batch), dim3(C::THREADS), C::LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipEventRecord(e2);
+            hipEventSynchronize(e2);
+            float f, i;
+            hipEventElapsedTime(&f, e0, e1); hipEventElapsedTime(&i, e1, e2);
+            if (r >= 2) { sf[k] += f; si[k] += i; bf[k] = f < bf[k] ? f : bf[k]; bi[k] = i < bi[k] ? i : bi[k]; }
+        }
     double bytes = 16.0 * n * batch;
-    printf("N=2^%d batch=%d  fwd avg %.4f ms (min %.4f) %.0f GB/s | inv avg %.4f ms (min %.4f) %.0f GB/s\n", log_n, batch,
-           sum_f / reps, best_f, bytes / (sum_f / reps * 1e-3) / 1e9, sum_i / reps, best_i, bytes / (sum_i / reps * 1e-3) / 1e9);
+    if (LAB_LOG_N == 14) {
+        for (auto &v : v14) {
+            hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+            hipFuncSetAttribute((const void *)v.i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+            // correctness first: forward must equal the generic kernel's forward, round trip must be the identity
+            std::vector<u64> ref(h.size()), got(h.size());
+            hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(vars[0].f, dim3(batch), dim3(C::THREADS), C::LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipMemcpy(ref.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            size_t badf = 0, badi = 0;
+            for (size_t i = 0; i < h.size(); ++i) badf += got[i] != ref[i];
+            hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < h.size(); ++i) badi += got[i] != h[i];
+            float sf2 = 0, si2 = 0;
+            for (int r = 0; r < reps + 2; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e1);
+                hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e2);
+                hipEventSynchronize(e2);
+                float f, i;
+                hipEventElapsedTime(&f, e0, e1); hipEventElapsedTime(&i, e1, e2);
+                if (r >= 2) { sf2 += f; si2 += i; }
+            }
+            printf("%-36s fwd avg %.4f ms %5.0f GB/s | inv avg %.4f ms %5.0f GB/s | fwd mismatches %zu, round-trip mismatches %zu\n", v.name,
+                   sf2 / reps, bytes / (sf2 / reps * 1e-3) / 1e9, si2 / reps, bytes / (si2 / reps * 1e-3) / 1e9, badf, badi);
+        }
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    }
+    for (int k = 0; k < nv; ++k)
+        printf("%-36s fwd avg %.4f ms (min %.4f) %5.0f GB/s | inv avg %.4f ms (min %.4f) %5.0f GB/s\n", vars[k].name, sf[k] / reps, bf[k],
+               bytes / (sf[k] / reps * 1e-3) / 1e9, si[k] / reps, bi[k], bytes / (si[k] / reps * 1e-3) / 1e9);
 #if !defined(FHE_ABLATE_NO_COMPUTE) && !defined(FHE_ABLATE_NO_GLOBAL)
     std::vector<u64> out(h.size());
     hipMemcpy(out.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
