@@ -1,0 +1,203 @@
+// Arithmetic policies shared by every transform kernel, and the in-register radix-2^R butterfly networks built on them.
+//
+//   ArithShoup   any prime q < 2^62: Shoup multiplication by the fixed twiddle {w, floor(w 2^64 / q)} + Harvey lazy
+//                reduction (forward values in [0, 4q), inverse in [0, 2q)).
+//   ArithPM<B>   pseudo-Mersenne primes q = 2^B - c (c <= 2^(B-33), 34 <= B <= 60): every prime
+//                `two_adic_primes(bits, log_n)` (util/src/zq.rs:325-329) yields for the BASELINE configs.
+//
+// Both leave canonical values in [0, q) when a kernel finishes: results are bit-identical to the reference's
+// `(a * b) as u128 % q` arithmetic (util/src/zq.rs:156-196) whichever policy ran.
+#pragma once
+#include <type_traits>
+
+#include "dev_arith.hpp"
+
+namespace fhe {
+
+template <int I, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, END>(f);
+    }
+}
+
+// per-modulus constants as the kernels read them from HBM (one entry per RNS limb)
+struct ModDesc {
+    u64 q;
+    const TwPair *tw, *twi;
+    u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
+    u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
+    // pseudo-Mersenne fast path: q = 2^pm_b - pm_c, twiddles in PmTw form; pm_b = 0: not eligible
+    const u64 *tww, *twwi;
+    unsigned pm_c;
+    int pm_b;
+};
+
+struct ArithShoup {
+    struct K {
+        u64 q, q2;
+        const TwPair *tw, *twi;
+        u64 ninv, ninv_s;
+        int pb, prefix;
+    };
+    static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
+        return K{D.q, 2 * D.q, D.tw, D.twi, pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix};
+    }
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
+        const TwPair p = k.tw[idx];
+        ct_bfly(X, Y, p.w, p.ws, k.q, k.q2);
+    }
+    template <int PH>
+    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
+        const TwPair p = k.twi[idx];
+        gs_bfly(X, Y, p.w, p.ws, k.q, k.q2);
+    }
+    static constexpr bool GS_FOLDS = false;
+    static constexpr bool JIT_TWIDDLES = true;
+    static __device__ __forceinline__ u64 gs_fold(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
+    static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(mul_shoup_lazy(x, k.ninv, k.ninv_s, k.q), k.q); }
+};
+
+// Pseudo-Mersenne product, q = 2^B - c (c < 2^(B-33), 34 <= B <= 60).
+// On gfx950 every integer VALU instruction costs about the same issue time (~16 lanes/clk/SIMD; v_mul_lo/hi_u32 twice
+// that), v_mad_u64_u32 included, so the product is arranged to need as FEW instructions as possible, all word aligned:
+// the fixed operand w is split at B-31 bits, w = wl + wh 2^(B-31) (wh < 2^31), and stored with wlp = wl << (63-B) and
+// wh2 = 2 wh, so that with y = y0 + y1 2^32 (any y < 2^63)
+//     w y = z0 + z1 2^(B-31) + wh y1 2^(B+1),  z0 = wl y0,  z1 = wh y0 + wlp y1 < 2^64 (no carry),  2^(B+1) = 2c,
+//     z1 2^(B-31) = (z1 >> 31) c + (z1 mod 2^31) 2^(B-31),
+//     w y = v + u c (mod q),   v = z0 + (z1 mod 2^31) 2^(B-31),   u = wh2 y1 + (z1 >> 31) < 2^63 + 2^33,
+// followed by one fold of the 96-bit v + u c at bit B.  8 multiply-adds + 5 other instructions, no compare/select, no
+// companion table.  Result < 2^B + 2^(63 + 2k - B) <= 1.25 * 2^B   (k = bits of c).
+struct PmTw {  // one twiddle, 16 bytes
+    unsigned wl, wlp, wh, wh2;
+};
+struct PmK {
+    u64 q, q2, q4;
+    unsigned c;
+};
+
+// a * b + c as ONE v_mad_u64_u32 even where the compiler would strength-reduce a power-of-two multiplier into a 64-bit
+// shift plus a 64-bit add (two instructions of the same issue cost each)
+__device__ __forceinline__ u64 mad_u64(unsigned a, unsigned b, u64 c) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int B>
+__device__ __forceinline__ u64 pm_mul(u64 y, const PmTw w, const PmK &k) {
+    constexpr unsigned M31 = 0x7fffffffu, HMASK = (1u << (B - 32)) - 1;
+    const unsigned y0 = (unsigned)y, y1 = (unsigned)(y >> 32);
+    const u64 z0 = (u64)w.wl * y0;
+    const u64 z1 = (u64)w.wh * y0 + (u64)w.wlp * y1;
+    const u64 v = mad_u64((unsigned)z1 & M31, 1u << (B - 31), z0);
+    const u64 u = (u64)w.wh2 * y1 + (z1 >> 31);
+    const u64 r1 = (u64)(unsigned)u * k.c + v;
+    const u64 r2 = (u64)(unsigned)(u >> 32) * k.c + (r1 >> 32);  // v + u c = r2 * 2^32 + lo32(r1)
+    const unsigned h2 = (unsigned)(r2 >> (B - 32));
+    const u64 l2 = ((u64)((unsigned)r2 & HMASK) << 32) | (unsigned)r1;
+    return (u64)h2 * k.c + l2;
+}
+
+// B = bit length of q (compile time: every shift and mask is an immediate)
+template <int B>
+struct ArithPM {
+    static constexpr u64 MASK = (u64(1) << B) - 1;
+    struct K {
+        PmK m;
+        const PmTw *tw, *twi;
+        PmTw ninv;  // n^-1 (or 1) in twiddle form
+        int pb, prefix;
+    };
+    static __host__ __device__ __forceinline__ PmTw split(u64 w) {
+        PmTw t;
+        t.wl = (unsigned)(w & ((u64(1) << (B - 31)) - 1));
+        t.wlp = t.wl << (63 - B);
+        t.wh = (unsigned)(w >> (B - 31));
+        t.wh2 = t.wh << 1;
+        return t;
+    }
+    static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
+        K k;
+        k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
+        k.m.c = D.pm_c;
+        k.tw = reinterpret_cast<const PmTw *>(D.tww); k.twi = reinterpret_cast<const PmTw *>(D.twwi);
+        k.ninv = split(pb ? 1 : D.ninv[log_n_total]);
+        k.pb = pb; k.prefix = prefix;
+        return k;
+    }
+    // x mod~ q: < 2^B + 2^(64-B) c
+    static __device__ __forceinline__ u64 fold1(u64 x, const PmK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
+    // Forward butterfly without any reduction.  Values grow by at most 2q per layer; a multiplicand must stay below 2^63
+    // and a sum below 2^64, which holds for 4 layers after a fold (inputs < q + eps -> multiplicands < 7q, outputs < 9q).
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
+        const u64 t = pm_mul<B>(Y, k.tw[idx], k.m);
+        const u64 x = X;
+        X = x + t;
+        Y = x - t + k.m.q2;
+    }
+    // Inverse butterflies come in pairs of layers: PH = 0 takes inputs < q + eps (outputs: sum < 2q + , product < q +),
+    // PH = 1 takes those (outputs: sum < 4q +, product < q +); the sums of a PH = 1 layer are folded (gs_fold) before the
+    // next pair.
+    template <int PH>
+    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
+        const u64 s = X + Y;
+        const u64 d = X - Y + (PH ? k.m.q4 : k.m.q2);
+        X = s;
+        Y = pm_mul<B>(d, k.twi[idx], k.m);
+    }
+    static constexpr bool GS_FOLDS = true;
+    static constexpr bool JIT_TWIDDLES = true;
+    static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }
+    static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
+    static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
+    static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(pm_mul<B>(x, k.ninv, k.m), k.m.q); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// radix-2^R butterfly networks on x[OFF .. OFF + 2^R): layers L0 .. L0+R-1 of a (sub-)transform
+// ---------------------------------------------------------------------------------------------------------
+template <class A, int L0, int R, int OFF, int E>
+__device__ __forceinline__ void ct_net(u64 (&x)[E], int top, const typename A::K &k) {
+#pragma unroll
+    for (int l = 0; l < R; ++l) {
+        const int half = 1 << (R - 1 - l);
+        // keep the twiddle loads of a layer inside that layer: hoisting all 2^R - 1 of them to the top of the pass costs
+        // more registers than the kernel has (two workgroups per CU leave 128 VGPRs per thread)
+        if (A::JIT_TWIDDLES && l > 0) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < (1 << l); ++b) {
+            const int idx = (1 << (L0 + l + k.pb)) + ((((k.prefix << L0) | top)) << l) + b;
+#pragma unroll
+            for (int j = 0; j < half; ++j) A::ct(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], idx, k);
+        }
+    }
+}
+
+template <class A, int L0, int R, int OFF, int E>
+__device__ __forceinline__ void gs_net(u64 (&x)[E], int top, const typename A::K &k) {
+    static_for<0, R>([&](auto step_c) {
+        constexpr int step = decltype(step_c)::value;  // 0 .. R-1, layer l = R-1-step
+        constexpr int l = R - 1 - step;
+        constexpr int PH = step & 1;
+        constexpr int half = 1 << (R - 1 - l);
+        if (A::JIT_TWIDDLES && step > 0) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < (1 << l); ++b) {
+            const int idx = (1 << (L0 + l + k.pb)) + ((((k.prefix << L0) | top)) << l) + b;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                A::template gs<PH>(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], idx, k);
+                // sums are folded after every second layer, and after the last layer of a network with an odd layer count,
+                // so that every network starts from values < q + eps
+                if constexpr (A::GS_FOLDS && (PH == 1 || step == R - 1)) x[OFF + b * 2 * half + j] = A::gs_fold(x[OFF + b * 2 * half + j], k);
+            }
+        }
+    });
+}
+
+
+}  // namespace fhe

@@ -55,17 +55,16 @@ inline unsigned grid_for(size_t total) {
     return (unsigned)(b > 8192 ? 8192 : (b ? b : 1));
 }
 
-fhe::RingConsts ring_consts(const fhe_ctx *c, int log_n) {
+fhe::RingConsts ring_consts(const fhe_ctx *c, int) {
     fhe::RingConsts K;
-    K.q = c->q;
-    K.q2 = 2 * c->q;
-    K.tw = c->d_tw;
-    K.twi = c->d_twi;
-    K.ninv = c->ninv[log_n];
-    K.ninv_s = c->ninv_s[log_n];
+    K.desc = c->d_desc;
     K.B = c->barrett;
     return K;
 }
+
+// fused kernels are instantiated for Shoup arithmetic (any prime) at every supported degree and for the 54-bit
+// pseudo-Mersenne primes (BASELINE config 3's modulus) at N = 512 .. 2048
+inline bool use_pm54(const fhe_ctx *c, int log_n) { return c->pm_b == 54 && log_n >= 9; }
 
 #define FHEW_DISPATCH(log_n, ...)                                          \
     switch (log_n) {                                                       \
@@ -229,13 +228,25 @@ static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bo
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
     if (ma.rc != FHE_OK || mb.rc != FHE_OK) return FHE_ERR_HIP;
     const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
-    FHEW_DISPATCH(key->log_n, {
-        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;
-        rc = set_lds(fhe::gadget_product_kernel<LN>, lds);
-        if (rc != FHE_OK) return rc;
-        hipLaunchKernelGGL(fhe::gadget_product_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, ma.d, mb.d,
-                           (unsigned)batch, key_view(key), (unsigned)index, both ? 1u : 0u, tt, ring_consts(ctx, LN));
-    });
+#define GP_LAUNCH(AR, LN)                                                                                              \
+    {                                                                                                                  \
+        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;                                \
+        rc = set_lds(fhe::gadget_product_kernel<AR, LN>, lds);                                                          \
+        if (rc != FHE_OK) return rc;                                                                                    \
+        hipLaunchKernelGGL((fhe::gadget_product_kernel<AR, LN>), dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, ma.d, \
+                           mb.d, (unsigned)batch, key_view(key), (unsigned)index, both ? 1u : 0u, tt, ring_consts(ctx, LN)); \
+    }
+    if (use_pm54(ctx, key->log_n)) {
+        switch (key->log_n) {
+            case 9: GP_LAUNCH(fhe::ArithPM<54>, 9) break;
+            case 10: GP_LAUNCH(fhe::ArithPM<54>, 10) break;
+            case 11: GP_LAUNCH(fhe::ArithPM<54>, 11) break;
+            default: return FHE_ERR_UNSUPPORTED;
+        }
+    } else {
+        FHEW_DISPATCH(key->log_n, GP_LAUNCH(fhe::ArithShoup, LN));
+    }
+#undef GP_LAUNCH
     HIP_TRY(hipGetLastError());
     rc = ma.sync_out(st);
     return rc != FHE_OK ? rc : mb.sync_out(st);
@@ -351,20 +362,28 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     BR.f = mf.d;
     BR.f_stride = f_stride;
     const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
-    switch (log_n) {
-#define BR_CASE(LN)                                                                                                         \
+#define BR_CASE(AR, LN)                                                                                                     \
     case LN: {                                                                                                              \
         const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;                                   \
-        rc = set_lds(fhe::blind_rotate_kernel<LN>, lds);                                                                    \
+        rc = set_lds(fhe::blind_rotate_kernel<AR, LN>, lds);                                                                \
         if (rc == FHE_OK)                                                                                                   \
-            hipLaunchKernelGGL(fhe::blind_rotate_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, BR, moa.d, \
-                               mob.d, (unsigned)batch, ring_consts(ctx, LN));                                              \
+            hipLaunchKernelGGL((fhe::blind_rotate_kernel<AR, LN>), dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, BR, \
+                               moa.d, mob.d, (unsigned)batch, ring_consts(ctx, LN));                                      \
         break;                                                                                                              \
     }
-        BR_CASE(7) BR_CASE(8) BR_CASE(9) BR_CASE(10) BR_CASE(11)
-#undef BR_CASE
-        default: return fail(FHE_ERR_UNSUPPORTED);
+    if (use_pm54(ctx, log_n)) {
+        switch (log_n) {
+            BR_CASE(fhe::ArithPM<54>, 9) BR_CASE(fhe::ArithPM<54>, 10) BR_CASE(fhe::ArithPM<54>, 11)
+            default: return fail(FHE_ERR_UNSUPPORTED);
+        }
+    } else {
+        switch (log_n) {
+            BR_CASE(fhe::ArithShoup, 7) BR_CASE(fhe::ArithShoup, 8) BR_CASE(fhe::ArithShoup, 9) BR_CASE(fhe::ArithShoup, 10)
+            BR_CASE(fhe::ArithShoup, 11)
+            default: return fail(FHE_ERR_UNSUPPORTED);
+        }
     }
+#undef BR_CASE
     if (rc != FHE_OK || hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
     int h_err = 0;
     if (hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FHE_ERR_HIP);

@@ -101,28 +101,27 @@ __host__ __device__ __forceinline__ int key_perm(int e) {
     return (r >> 1) * 128 + lane * 2 + (r & 1);
 }
 
+// what a fused kernel needs besides its arithmetic policy's constants (policy K built from the ModDesc in-kernel)
 struct RingConsts {
-    u64 q, q2;
-    const TwPair *tw, *twi;
-    u64 ninv, ninv_s;
-    Barrett B;
+    const ModDesc *desc;  // the modulus, in HBM
+    Barrett B;            // variable x variable products of the multiply-accumulate
 };
 
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
-template <int LOG_N>
+template <class A, int LOG_N>
 __device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&sa)[1 << (LOG_N - 6)], u64 (&sb)[1 << (LOG_N - 6)],
-                                        const u64 *__restrict__ row, int lane, const RingConsts &K) {
+                                        const u64 *__restrict__ row, int lane, const RingConsts &K, const typename A::K &k) {
     constexpr int E = 1 << (LOG_N - 6), N = 1 << LOG_N;
     const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
     const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
 #pragma unroll
     for (int r2 = 0; r2 < E / 2; ++r2) {
         const ulonglong2 a = ka[r2 * 64 + lane], b = kb[r2 * 64 + lane];
-        const u64 x0 = canon4(x[2 * r2], K.q, K.q2), x1 = canon4(x[2 * r2 + 1], K.q, K.q2);
-        sa[2 * r2] = csub(sa[2 * r2] + mulmod_barrett(x0, a.x, K.B), K.q);
-        sa[2 * r2 + 1] = csub(sa[2 * r2 + 1] + mulmod_barrett(x1, a.y, K.B), K.q);
-        sb[2 * r2] = csub(sb[2 * r2] + mulmod_barrett(x0, b.x, K.B), K.q);
-        sb[2 * r2 + 1] = csub(sb[2 * r2 + 1] + mulmod_barrett(x1, b.y, K.B), K.q);
+        const u64 x0 = A::canon_fwd(x[2 * r2], k), x1 = A::canon_fwd(x[2 * r2 + 1], k);
+        sa[2 * r2] = csub(sa[2 * r2] + mulmod_barrett(x0, a.x, K.B), K.B.q);
+        sa[2 * r2 + 1] = csub(sa[2 * r2 + 1] + mulmod_barrett(x1, a.y, K.B), K.B.q);
+        sb[2 * r2] = csub(sb[2 * r2] + mulmod_barrett(x0, b.x, K.B), K.B.q);
+        sb[2 * r2 + 1] = csub(sb[2 * r2 + 1] + mulmod_barrett(x1, b.y, K.B), K.B.q);
     }
 }
 
@@ -133,40 +132,40 @@ __device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&
 //                 (a, b) <- (sum_j rows[j].a * limb_j, sum_j rows[j].b * limb_j + b)
 // Each limb is transformed by the wave-private NTT and multiplied into evaluation-domain sums; two inverse
 // transforms bring the result back.  (ca, cb): coefficient layout, canonical, in and out.
-template <int LOG_N>
+template <class A, int LOG_N>
 __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)], u64 (&cb)[1 << (LOG_N - 6)],
                                                     const u64 *__restrict__ rows, const DecompParams &P, bool both, int lane,
-                                                    u64 *lds, const RingConsts &K) {
+                                                    u64 *lds, const RingConsts &K, const typename A::K &k) {
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
     u64 sa[E], sb[E], st[E];
 #pragma unroll
-    for (int k = 0; k < E; ++k) { sa[k] = sb[k] = 0; st[k] = decomp_init(ca[k], P); }
+    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = decomp_init(ca[e], P); }
     const int total = both ? 2 * P.d : P.d;
 #pragma unroll 1
     for (int j = 0; j < total; ++j) {
         if (both && j == P.d) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) st[k] = decomp_init(cb[k], P);
+            for (int e = 0; e < E; ++e) st[e] = decomp_init(cb[e], P);
         }
         u64 x[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = decomp_next(st[k], P);
-        fwd_run<typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, TwSel{K.tw, 0, 0}, K.q, K.q2);
-        mac_row<LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, K);
+        for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
+        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, k);
+        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, K, k);
     }
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, TwSel{K.twi, 0, 0}, K.q, K.q2, K.ninv, K.ninv_s);
+        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, k);
 #pragma unroll
-        for (int k = 0; k < E; ++k) { const u64 t = sa[k]; sa[k] = sb[k]; sb[k] = t; }
+        for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
     // after two swaps sa / sb are back in place
 #pragma unroll
-    for (int k = 0; k < E; ++k) {
-        ca[k] = sa[k];
-        cb[k] = both ? sb[k] : csub(sb[k] + cb[k], K.q);
+    for (int e = 0; e < E; ++e) {
+        ca[e] = sa[e];
+        cb[e] = both ? sb[e] : csub(sb[e] + cb[e], K.B.q);
     }
 }
 
@@ -210,7 +209,7 @@ struct FhewKey {      // device view of a prepared gadget key set
 // batched gadget product, every ciphertext against key entry `index`:
 //   both = 1: RLWE x RGSW external product; both = 0: RLWE key switch, preceded by X -> X^t2n when t2n != 1
 //   (scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism`)
-template <int LOG_N>
+template <class A, int LOG_N>
 __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void gadget_product_kernel(
     u64 *__restrict__ ct_a, u64 *__restrict__ ct_b, unsigned batch, FhewKey key, unsigned index, unsigned both, unsigned t2n,
     RingConsts K) {
@@ -220,14 +219,15 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void gadget_product_kern
     const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
     if (ct >= batch) return;  // wave-uniform exit; no workgroup barrier is used anywhere
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
     u64 ca[W::E], cb[W::E];
     wave_load<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
     wave_load<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
     if (t2n != 1) {
-        wave_automorphism<LOG_N>(ca, t2n, lane, lds, K.q);
-        wave_automorphism<LOG_N>(cb, t2n, lane, lds, K.q);
+        wave_automorphism<LOG_N>(ca, t2n, lane, lds, K.B.q);
+        wave_automorphism<LOG_N>(cb, t2n, lane, lds, K.B.q);
     }
-    wave_gadget_product<LOG_N>(ca, cb, key.rows + size_t(index) * key.rows_per_ct * 2 * W::N, key.P, both != 0, lane, lds, K);
+    wave_gadget_product<A, LOG_N>(ca, cb, key.rows + size_t(index) * key.rows_per_ct * 2 * W::N, key.P, both != 0, lane, lds, K, k);
     wave_store<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
     wave_store<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
 }
@@ -322,7 +322,7 @@ struct BlindRotateParams {
     size_t f_stride;      // 0: one f for the whole batch, N: one per ciphertext
 };
 
-template <int LOG_N>
+template <class A, int LOG_N>
 __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
                                                                                   u64 *__restrict__ out_b, unsigned batch, RingConsts K) {
     using W = WaveRing<LOG_N>;
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel
     const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
     if (ct >= batch) return;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
     u64 ca[E], cb[E];
     // acc = (0, f.automorphism(-g) * X^(b*g))   (bootstrapping.rs:165-167); both steps are signed index maps
     {
@@ -340,16 +341,16 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel
         const unsigned kmono = (b * 5u) & (2 * N - 1);  // (b * g) mod 2N; X^k with k taken mod 2N
         const unsigned tneg = (2 * N - 5u) & (2 * N - 1);
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const unsigned i = coef_index<LOG_N>(lane, k);
+        for (int e = 0; e < E; ++e) {
+            const unsigned i = coef_index<LOG_N>(lane, e);
             const u64 v = f[i];
             unsigned pos = (i * tneg) & (2 * N - 1);   // automorphism(-5): X^i -> X^(i t)
             pos = (pos + kmono) & (2 * N - 1);         // * X^k
-            lds[lds_phys(pos & (N - 1))] = pos < N ? v : (v ? K.q - v : 0);
+            lds[lds_phys(pos & (N - 1))] = pos < N ? v : (v ? K.B.q - v : 0);
         }
         exchange_sync<true>();
 #pragma unroll
-        for (int k = 0; k < E; ++k) { cb[k] = lds[lds_phys(coef_index<LOG_N>(lane, k))]; ca[k] = 0; }
+        for (int e = 0; e < E; ++e) { cb[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))]; ca[e] = 0; }
         exchange_sync<true>();
     }
     const unsigned *ops = BR.ops + size_t(ct) * BR.max_ops;
@@ -360,11 +361,11 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel
         const unsigned idx = op & 0x7fffffffu;
         if (is_ak) {
             const unsigned t = BR.ak_t[idx];
-            wave_automorphism<LOG_N>(ca, t, lane, lds, K.q);
-            wave_automorphism<LOG_N>(cb, t, lane, lds, K.q);
+            wave_automorphism<LOG_N>(ca, t, lane, lds, K.B.q);
+            wave_automorphism<LOG_N>(cb, t, lane, lds, K.B.q);
         }
         const FhewKey &key = is_ak ? BR.ak : BR.brk;
-        wave_gadget_product<LOG_N>(ca, cb, key.rows + size_t(idx) * key.rows_per_ct * 2 * N, key.P, !is_ak, lane, lds, K);
+        wave_gadget_product<A, LOG_N>(ca, cb, key.rows + size_t(idx) * key.rows_per_ct * 2 * N, key.P, !is_ak, lane, lds, K, k);
     }
     wave_store<LOG_N>(ca, out_a + size_t(ct) * N, lane);
     wave_store<LOG_N>(cb, out_b + size_t(ct) * N, lane);

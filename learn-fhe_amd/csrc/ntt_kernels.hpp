@@ -12,9 +12,7 @@
 // Cooley-Tukey layers 0..logN-1 with twiddle tw[2^layer + i], natural in / bit-reversed out;
 // inverse = Gentleman-Sande layers logN-1..0 with twi[2^layer + i], then * n^-1.
 #pragma once
-#include <type_traits>
-
-#include "dev_arith.hpp"
+#include "arith.hpp"
 
 namespace fhe {
 
@@ -34,28 +32,6 @@ struct NttCfg {
 
 __device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }
 
-// Twiddle selector of one transform: table + the sub-transform prefix.  A ring of degree 2^(LOG_N + pb) is
-// processed as one radix-2^pb pass over the whole polynomial followed by 2^pb independent sub-transforms of
-// size 2^LOG_N; sub-transform `prefix` continues at layer pb with twiddle index
-// 2^(l + pb) + (prefix << l) + i  (the reference's tw[m + i], util/src/ring/fft.rs:43-53, restricted to a block).
-struct TwSel {
-    const TwPair *tw;
-    int pb;
-    int prefix;
-};
-
-// per-modulus constants as the kernels read them from HBM (one entry per RNS limb)
-struct ModDesc {
-    u64 q;
-    const TwPair *tw, *twi;
-    u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
-    u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
-    // pseudo-Mersenne fast path (ntt14.hpp): q = 2^pm_b - pm_c, plain twiddle tables (no companions); pm_b = 0: not eligible
-    const u64 *tww, *twwi;
-    unsigned pm_c;
-    int pm_b;
-};
-
 // DIRECT (template flag of the transform kernels): the pass that owns 2^LOG_E contiguous coefficients per thread
 // (last forward pass, first inverse pass) moves them between registers and HBM itself with 16-byte accesses
 // (each thread owns whole 128-byte lines) instead of staging the polynomial through LDS once more.  Measured on
@@ -70,51 +46,12 @@ __device__ __forceinline__ u64 gload(const u64 *p, int i) { return p[i]; }
 __device__ __forceinline__ void gstore(u64 *p, int i, u64 v) { p[i] = v; }
 #endif
 
-template <int I, int END, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < END) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, END>(f);
-    }
-}
-
 // element index of register r of butterfly group `grp` in the pass that covers layers [L0, L0+R)
 template <int LOG_N, int L0, int R>
 __device__ __forceinline__ int pass_index(int grp, int r) {
     constexpr int h = LOG_N - L0 - R;
     const int top = grp >> h, low = grp & ((1 << h) - 1);
     return (top << (h + R)) | (r << h) | low;
-}
-
-// ---------------------------------------------------------------------------------------------
-// in-register radix-2^R passes on x[OFF .. OFF + 2^R)
-// ---------------------------------------------------------------------------------------------
-template <int L0, int R, int OFF, int E>
-__device__ __forceinline__ void fwd_pass_regs(u64 (&x)[E], int top, const TwSel tw, u64 q, u64 q2) {
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int half = 1 << (R - 1 - k);
-#pragma unroll
-        for (int b = 0; b < (1 << k); ++b) {
-            const TwPair p = tw.tw[(1 << (L0 + k + tw.pb)) + ((((tw.prefix << L0) | top)) << k) + b];
-#pragma unroll
-            for (int j = 0; j < half; ++j) ct_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
-        }
-    }
-}
-
-template <int L0, int R, int OFF, int E>
-__device__ __forceinline__ void inv_pass_regs(u64 (&x)[E], int top, const TwSel twi, u64 q, u64 q2) {
-#pragma unroll
-    for (int k = R - 1; k >= 0; --k) {
-        const int half = 1 << (R - 1 - k);
-#pragma unroll
-        for (int b = 0; b < (1 << k); ++b) {
-            const TwPair p = twi.tw[(1 << (L0 + k + twi.pb)) + ((((twi.prefix << L0) | top)) << k) + b];
-#pragma unroll
-            for (int j = 0; j < half; ++j) gs_bfly(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], p.w, p.ws, q, q2);
-        }
-    }
 }
 
 // wave-uniform `top` can be moved to an SGPR so the twiddle loads become scalar loads
@@ -140,9 +77,9 @@ __device__ __forceinline__ void exchange_sync() {
 // x[gg*2^R0 + r]) and gets the evaluations back in x[] in the last pass's layout (coefficient t*E + r at
 // x[r]), still lazy in [0, 4q); nothing touches global memory.
 // ---------------------------------------------------------------------------------------------
-template <typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>
+template <class A, typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>
 __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
-                                        const TwSel tw, u64 q, u64 q2) {
+                                        const typename A::K &k) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (L0 == 0) ? C::R0 : LOG_E;
     constexpr int G = E >> R;  // butterfly groups per thread in this pass
@@ -161,12 +98,16 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             }
         }
     }
-    // butterflies
+    // butterflies (lazy values are folded back at every pass boundary where the policy needs it)
+    if constexpr (!first) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) x[r] = A::fold(x[r], k);
+    }
     static_for<0, G>([&](auto gg_c) {
         constexpr int gg = decltype(gg_c)::value;
         const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
 #ifndef FHE_ABLATE_NO_COMPUTE
-        fwd_pass_regs<L0, R, gg * (1 << R), E>(x, top, tw, q, q2);
+        ct_net<A, L0, R, gg * (1 << R), E>(x, top, k);
 #endif
     });
     // store
@@ -177,7 +118,7 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r)
-                if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), canon4(x[gg * (1 << R) + r], q, q2));
+                if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), A::canon_fwd(x[gg * (1 << R) + r], k));
     } else if constexpr (last && DIRECT) {
         // h == 0: register r holds coefficient (t << LOG_E) + r
         static_assert(G == 1, "last pass is a full pass");
@@ -186,8 +127,8 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < E; r += 2) {
                 ulonglong2 v;
-                v.x = canon4(x[r], q, q2);
-                v.y = canon4(x[r + 1], q, q2);
+                v.x = A::canon_fwd(x[r], k);
+                v.y = A::canon_fwd(x[r + 1], k);
 #ifdef FHE_ABLATE_NO_GLOBAL
                 if (v.x == 0xdeadbeefcafef00dull) dst[r >> 1] = v;
 #else
@@ -201,17 +142,17 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
                 u64 v = x[gg * (1 << R) + r];
-                if constexpr (last) v = canon4(v, q, q2);
+                if constexpr (last) v = A::canon_fwd(v, k);
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = v;
             }
         exchange_sync<WAVE>();
-        if constexpr (!last) fwd_run<C, LOG_N, LOG_E, L0 + R, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, tw, q, q2);
+        if constexpr (!last) fwd_run<A, C, LOG_N, LOG_E, L0 + R, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, k);
     }
 }
 
 // data: `subs` sub-polynomials of size 2^LOG_N, contiguous; sub s belongs to polynomial s >> pb (modulus descriptor
 // (s >> pb) % n_desc) and is its sub-transform number s & (2^pb - 1).  pb = 0: plain transforms.
-template <int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = false>
+template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = false>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_kernel(
     u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
     const int pb = PFX ? pb_arg : 0;  // PFX = false: every twiddle index folds to a constant expression
@@ -221,19 +162,17 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
     const unsigned poly = blockIdx.x * PPW + pw;
     const bool active = poly < subs;
     const ModDesc &D = descs[((active ? poly : 0u) >> pb) % n_desc];
-    const u64 q = D.q;
-    const TwSel tw{D.tw, pb, int(poly & ((1u << pb) - 1))};
+    const typename A::K k = A::make(D, LOG_N, pb, int(poly & ((1u << pb) - 1)));
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
-    const u64 q2 = 2 * q;
-    fwd_run<C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, tw, q, q2);
+    fwd_run<A, C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, k);
     if constexpr (C::P > 1 && !DIRECT) {
         // the canonical image sits in LDS: stream it out with consecutive lanes on consecutive addresses
         if (active) {
 #pragma unroll
-            for (int k = 0; k < C::E; ++k) {
-                const int i = t + C::T * k;
+            for (int kk = 0; kk < C::E; ++kk) {
+                const int i = t + C::T * kk;
                 gstore(g, i, lds[lds_phys(i)]);
             }
         }
@@ -245,9 +184,9 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 // ---------------------------------------------------------------------------------------------
 // REGS_IO: x[] comes in in the last-layer pass layout (coefficient t*E + r at x[r], values in [0, 2q)) and
 // leaves in the first-pass layout, multiplied by n^-1 and canonical.
-template <typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>  // layers [L0, LEND)
+template <class A, typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>  // layers [L0, LEND)
 __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
-                                        const TwSel twi, u64 q, u64 q2, u64 ninv, u64 ninv_s) {
+                                        const typename A::K &k) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (LEND == C::R0) ? C::R0 : LOG_E;
     constexpr int L0 = LEND - R;
@@ -281,7 +220,7 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         constexpr int gg = decltype(gg_c)::value;
         const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
 #ifndef FHE_ABLATE_NO_COMPUTE
-        inv_pass_regs<L0, R, gg * (1 << R), E>(x, top, twi, q, q2);
+        gs_net<A, L0, R, gg * (1 << R), E>(x, top, k);
 #endif
     });
     if constexpr (final_pass) {
@@ -290,7 +229,7 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
-                const u64 v = csub(mul_shoup_lazy(x[gg * (1 << R) + r], ninv, ninv_s, q), q);
+                const u64 v = A::finish_inv(x[gg * (1 << R) + r], k);
                 if constexpr (REGS_IO) x[gg * (1 << R) + r] = v;
                 else if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), v);
             }
@@ -301,11 +240,11 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             for (int r = 0; r < (1 << R); ++r)
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = x[gg * (1 << R) + r];
         exchange_sync<WAVE>();
-        inv_run<C, LOG_N, LOG_E, L0, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+        inv_run<A, C, LOG_N, LOG_E, L0, REGS_IO, WAVE, DIRECT>(x, t, g, lds, active, k);
     }
 }
 
-template <int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = true>
+template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = true>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_kernel(
     u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
     const int pb = PFX ? pb_arg : 0;
@@ -315,23 +254,20 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
     const unsigned poly = blockIdx.x * PPW + pw;
     const bool active = poly < subs;
     const ModDesc &D = descs[((active ? poly : 0u) >> pb) % n_desc];
-    const u64 q = D.q;
-    const TwSel twi{D.twi, pb, int(poly & ((1u << pb) - 1))};
-    // with pb > 0 the n^-1 scaling belongs to the closing radix-2^pb pass: multiply by 1 here
-    const u64 ninv = pb ? 1 : D.ninv[LOG_N], ninv_s = pb ? D.one_s : D.ninv_s[LOG_N];
+    // with pb > 0 the n^-1 scaling belongs to the closing radix-2^pb pass (make() then scales by 1)
+    const typename A::K k = A::make(D, LOG_N, pb, int(poly & ((1u << pb) - 1)));
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
-    const u64 q2 = 2 * q;
     if constexpr (C::P > 1 && !DIRECT) {
 #pragma unroll
-        for (int k = 0; k < C::E; ++k) {
-            const int i = t + C::T * k;
+        for (int kk = 0; kk < C::E; ++kk) {
+            const int i = t + C::T * kk;
             lds[lds_phys(i)] = active ? gload(g, i) : 0;
         }
         __syncthreads();
     }
-    inv_run<C, LOG_N, LOG_E, LOG_N, false, false, DIRECT>(x, t, g, lds, active, twi, q, q2, ninv, ninv_s);
+    inv_run<A, C, LOG_N, LOG_E, LOG_N, false, false, DIRECT>(x, t, g, lds, active, k);
 }
 
 // Opening radix-2^PB pass of a ring of degree 2^log_n (layers 0..PB-1 across the 2^PB blocks), one thread per
@@ -349,7 +285,8 @@ __global__ void ntt_big_fwd_pass(u64 *__restrict__ data, const ModDesc *__restri
         u64 x[1 << PB];
 #pragma unroll
         for (int r = 0; r < (1 << PB); ++r) x[r] = g[size_t(r) << lc];
-        fwd_pass_regs<0, PB, 0, (1 << PB)>(x, 0, TwSel{D.tw, 0, 0}, q, q2);
+        const ArithShoup::K k = ArithShoup::make(D, log_n, 0, 0);
+        ct_net<ArithShoup, 0, PB, 0, (1 << PB)>(x, 0, k);
 #pragma unroll
         for (int r = 0; r < (1 << PB); ++r) g[size_t(r) << lc] = canon4(x[r], q, q2);
     }
@@ -369,7 +306,8 @@ __global__ void ntt_big_inv_pass(u64 *__restrict__ data, const ModDesc *__restri
         u64 x[1 << PB];
 #pragma unroll
         for (int r = 0; r < (1 << PB); ++r) x[r] = g[size_t(r) << lc];
-        inv_pass_regs<0, PB, 0, (1 << PB)>(x, 0, TwSel{D.twi, 0, 0}, q, q2);
+        const ArithShoup::K k = ArithShoup::make(D, log_n, 0, 0);
+        gs_net<ArithShoup, 0, PB, 0, (1 << PB)>(x, 0, k);
 #pragma unroll
         for (int r = 0; r < (1 << PB); ++r) g[size_t(r) << lc] = csub(mul_shoup_lazy(x[r], D.ninv[log_n], D.ninv_s[log_n], q), q);
     }

@@ -108,9 +108,9 @@ int main(int argc, char **argv) {
         {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw>, ntt14_inv_kernel<ArithNoTw>},
     };
     Variant vars[] = {
-        {"fwd staged / inv direct (product)", ntt_fwd_kernel<LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<LAB_LOG_N, 4, 1, false, true>},
-        {"fwd direct / inv staged", ntt_fwd_kernel<LAB_LOG_N, 4, 1, false, true>, ntt_inv_kernel<LAB_LOG_N, 4, 1, false, false>},
-        {"runtime prefix (pb arg honoured)", ntt_fwd_kernel<LAB_LOG_N, 4, 1, true, false>, ntt_inv_kernel<LAB_LOG_N, 4, 1, true, true>},
+        {"generic Shoup, fwd staged / inv direct", ntt_fwd_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, true>},
+        {"generic pseudo-Mersenne (product)", ntt_fwd_kernel<ArithPM<60>, LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<ArithPM<60>, LAB_LOG_N, 4, 1, false, true>},
+        {"generic pseudo-Mersenne, fwd direct", ntt_fwd_kernel<ArithPM<60>, LAB_LOG_N, 4, 1, false, true>, ntt_inv_kernel<ArithPM<60>, LAB_LOG_N, 4, 1, false, false>},
     };
     const int nv = sizeof(vars) / sizeof(vars[0]);
     for (auto &v : vars) {
@@ -166,7 +166,41 @@ int main(int argc, char **argv) {
             printf("%-36s fwd avg %.4f ms %5.0f GB/s | inv avg %.4f ms %5.0f GB/s | fwd mismatches %zu, round-trip mismatches %zu\n", v.name,
                    sf2 / reps, bytes / (sf2 / reps * 1e-3) / 1e9, si2 / reps, bytes / (si2 / reps * 1e-3) / 1e9, badf, badi);
         }
+        {   // occupancy experiment: the same kernel with 100 KiB of dynamic LDS requested -> ONE workgroup per CU
+            const size_t big = 100 * 1024;
+            hipFuncSetAttribute((const void *)v14[1].f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+            float sf2 = 0;
+            for (int r = 0; r < reps + 2; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(v14[1].f, dim3(batch), dim3(N14_THREADS), big, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float f; hipEventElapsedTime(&f, e0, e1);
+                if (r >= 2) sf2 += f;
+            }
+            printf("ntt14 pseudo-Mersenne fwd, 1 workgroup per CU (100 KiB LDS requested): %.4f ms\n", sf2 / reps);
+        }
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+#ifdef NTT14_STAMPS
+        {   // where does a workgroup spend its life?  (forward pseudo-Mersenne kernel, the last launch)
+            hipLaunchKernelGGL(v14[1].f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+            hipDeviceSynchronize();
+            static unsigned long long hs[4096][16];
+            hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+            const char *names[] = {"HBM load", "pass0", "xchg01", "pass1", "xchg12", "pass2", "xchg23", "pass3", "store"};
+            double sum[9] = {0}; double life = 0; int cnt = 0;
+            for (int b = 0; b < batch && b < 4096; ++b) {
+                if (hs[b][9] <= hs[b][0]) continue;
+                for (int p = 0; p < 9; ++p) sum[p] += double(hs[b][p + 1] - hs[b][p]);
+                life += double(hs[b][9] - hs[b][0]); ++cnt;
+            }
+            printf("stamps (s_memtime ticks, avg over %d workgroups; lifetime %.0f):\n", cnt, life / cnt);
+            for (int p = 0; p < 9; ++p) printf("  %-9s %8.0f (%4.1f%%)\n", names[p], sum[p] / cnt, 100.0 * sum[p] / life);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < batch && b < 4096; ++b) { if (hs[b][0] < t0) t0 = hs[b][0]; if (hs[b][9] > t1) t1 = hs[b][9]; }
+            printf("  kernel span %llu ticks\n", t1 - t0);
+        }
+#endif
     }
     for (int k = 0; k < nv; ++k)
         printf("%-36s fwd avg %.4f ms (min %.4f) %5.0f GB/s | inv avg %.4f ms (min %.4f) %5.0f GB/s\n", vars[k].name, sf[k] / reps, bf[k],
