@@ -55,6 +55,43 @@ def cpu_baseline(sample_per_thread=48):
             "single_thread_value": single}
 
 
+def fhew_bench(torch, F, dev, local_rank, batches=(64, 1024), reps=3):
+    """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
+    rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
+    N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident."""
+    from oracle import pyref as P  # only ak_t(): the exponent list [-5, 5, 25, ...] mod 2N
+    q, n, log_b, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 100
+    ctx = F.NttContext(q, device=local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    rnd = lambda *shape: torch.randint(0, q, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
+    brk = F.GadgetKey(ctx, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n, rgsw=True)
+    ak = F.GadgetKey(ctx, log_b, d, rnd(w + 1, d, n), rnd(w + 1, d, n), n, rgsw=False)
+    bk = F.BootstrapKey(ctx, brk, ak, P.ak_t(n, w), w)
+    f = rnd(n)
+    out = {"workload": "cfg3: LMKCDEY blind rotation N=2^10 q=%d log_b=6 d=9 n_lwe=100 w=10" % q}
+    for batch in batches:
+        lwe_a = torch.randint(0, n, (batch, n_lwe), dtype=torch.int64, device=dev, generator=gen) * 2 + 1
+        lwe_b = torch.randint(0, 2 * n, (batch,), dtype=torch.int64, device=dev, generator=gen)
+        bk.blind_rotate(lwe_a, lwe_b, f)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            bk.blind_rotate(lwe_a, lwe_b, f)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out["blind_rotations_per_sec_batch%d" % batch] = batch / dt
+    ca, cb = rnd(4096, n), rnd(4096, n)
+    brk.external_product_(0, ca, cb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        brk.external_product_(i % n_lwe, ca, cb)
+    torch.cuda.synchronize()
+    out["external_products_per_sec_batch4096"] = 10 * 4096 / (time.perf_counter() - t0)
+    return out
+
+
 def load_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), if any."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -73,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="polynomials per GPU (default: BASELINE cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the final all_gather of results (not in value)")
+    ap.add_argument("--no-fhew", action="store_true", help="skip the secondary FHEW blind-rotation figures")
     args = ap.parse_args()
 
     import torch
@@ -151,7 +189,7 @@ def main():
             "config": {"workload": "cfg2: batched forward+inverse negacyclic NTT, N=2^14, q=%d, batch=%d per GPU, "
                                    "HBM-resident" % (Q, args.batch), "n": n, "q": Q, "batch_per_gpu": args.batch,
                        "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<14,4,1>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<ArithPM<60>,14,4,1> (forward transform)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
@@ -159,6 +197,8 @@ def main():
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if n_gpus == 1 and not args.no_fhew:
+            out["fhew"] = fhew_bench(torch, F, dev, local_rank)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

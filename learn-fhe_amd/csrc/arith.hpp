@@ -59,6 +59,12 @@ struct ArithShoup {
     static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(mul_shoup_lazy(x, k.ninv, k.ninv_s, k.q), k.q); }
+    // evaluation-domain multiply-accumulate against a VARIABLE operand (key rows): x = forward-transform output (lazy)
+    static __device__ __forceinline__ u64 mac_in(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
+    static __device__ __forceinline__ u64 mac(u64 acc, u64 xin, u64 kval, int, const K &k, const Barrett &B) {
+        return csub(acc + mulmod_barrett(xin, kval, B), k.q);
+    }
+    static __device__ __forceinline__ u64 mac_finish(u64 acc, const K &) { return acc; }  // canonical: valid inverse input
 };
 
 // Pseudo-Mersenne product, q = 2^B - c (c < 2^(B-33), 34 <= B <= 60).
@@ -155,6 +161,17 @@ struct ArithPM {
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(pm_mul<B>(x, k.ninv, k.m), k.m.q); }
+    // multiply-accumulate against a variable operand: the key value is split on the fly (4 instructions), the lazy
+    // forward output (< 2^63) is the multiplicand as it stands, products (< 1.25 * 2^B) are summed without reduction and
+    // the running sum is folded every MAC_FOLD terms so it never reaches 2^64
+    static constexpr int MAC_FOLD = ((1 << (64 - B)) * 4 / 5 - 2) < 1 ? 1 : (((1 << (64 - B)) * 4 / 5 - 2) > 64 ? 64 : ((1 << (64 - B)) * 4 / 5 - 2));
+    static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 mac(u64 acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
+        u64 s = acc + pm_mul<B>(xin, split(kval), k.m);
+        if ((term % MAC_FOLD) == MAC_FOLD - 1) s = fold1(s, k.m);
+        return s;
+    }
+    static __device__ __forceinline__ u64 mac_finish(u64 acc, const K &k) { return fold1(acc, k.m); }  // < 2^B + eps
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -110,18 +110,18 @@ struct RingConsts {
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
 template <class A, int LOG_N>
 __device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&sa)[1 << (LOG_N - 6)], u64 (&sb)[1 << (LOG_N - 6)],
-                                        const u64 *__restrict__ row, int lane, const RingConsts &K, const typename A::K &k) {
+                                        const u64 *__restrict__ row, int lane, int term, const RingConsts &K, const typename A::K &k) {
     constexpr int E = 1 << (LOG_N - 6), N = 1 << LOG_N;
     const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
     const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
 #pragma unroll
     for (int r2 = 0; r2 < E / 2; ++r2) {
         const ulonglong2 a = ka[r2 * 64 + lane], b = kb[r2 * 64 + lane];
-        const u64 x0 = A::canon_fwd(x[2 * r2], k), x1 = A::canon_fwd(x[2 * r2 + 1], k);
-        sa[2 * r2] = csub(sa[2 * r2] + mulmod_barrett(x0, a.x, K.B), K.B.q);
-        sa[2 * r2 + 1] = csub(sa[2 * r2 + 1] + mulmod_barrett(x1, a.y, K.B), K.B.q);
-        sb[2 * r2] = csub(sb[2 * r2] + mulmod_barrett(x0, b.x, K.B), K.B.q);
-        sb[2 * r2 + 1] = csub(sb[2 * r2 + 1] + mulmod_barrett(x1, b.y, K.B), K.B.q);
+        const u64 x0 = A::mac_in(x[2 * r2], k), x1 = A::mac_in(x[2 * r2 + 1], k);
+        sa[2 * r2] = A::mac(sa[2 * r2], x0, a.x, term, k, K.B);
+        sa[2 * r2 + 1] = A::mac(sa[2 * r2 + 1], x1, a.y, term, k, K.B);
+        sb[2 * r2] = A::mac(sb[2 * r2], x0, b.x, term, k, K.B);
+        sb[2 * r2 + 1] = A::mac(sb[2 * r2 + 1], x1, b.y, term, k, K.B);
     }
 }
 
@@ -152,8 +152,10 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)],
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
         fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, k);
-        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, K, k);
+        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(sa[e], k); sb[e] = A::mac_finish(sb[e], k); }
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
