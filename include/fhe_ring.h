@@ -149,6 +149,42 @@ void fhe_ckks_key_destroy(fhe_ckks_key *key);
 int fhe_ckks_key_switch(const fhe_rns_ctx *rns, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch,
                         fhe_mem mem, void *stream);
 
+/* ---- TFHE torus path (row T), k = 1 ---------------------------------------------------------------------- */
+/* Torus data are uint64_t values of Z/2^64 (util/src/torus.rs `T64`).  Where the reference multiplies torus polynomials
+ * with an f64 FFT (util/src/ring/fft/c64.rs:11-56, error <= 2^(64+log_b+log_n-53), c64.rs:186-208), this backend returns
+ * the EXACT product (both operands read as signed 64-bit integers, as c64.rs:23-27 does): never less exact than the
+ * reference, identical at decode level. */
+typedef struct fhe_torus_ctx fhe_torus_ctx;   /* two 60-bit NTT primes + CRT constants */
+typedef struct fhe_tggsw_key fhe_tggsw_key;   /* prepared TGGSW ciphertexts (bootstrapping key) */
+int fhe_torus_ctx_create(int device, fhe_torus_ctx **out);
+void fhe_torus_ctx_destroy(fhe_torus_ctx *t);
+/* util/src/misc/decompose.rs:66-81, 114-135 `Base2Decomposor::<T64>::new(log_b, d).decompose(poly)`: [polys][n] ->
+ * [polys][d][n] signed digits as two's-complement uint64_t, least significant first.  Bit-exact. */
+int fhe_torus_decompose(int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream);
+/* util/src/ring.rs:315-320 `Rt *= &Rt`: a <- a * b in Z_{2^64}[X]/(X^n+1), exact; |b_i| < 2^log_bound_b with
+ * n * 2^(64 + log_bound_b) < 2^118 (gadget digits, small secrets: what the reference's FFT product is used for). */
+int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int log_bound_b, size_t n, size_t batch, fhe_mem mem,
+                  void *stream);
+/* `count` TGGSW ciphertexts (scheme/tfhe/src/tggsw.rs:44-88): rows_a / rows_b [count][2d][n].  n = 256 .. 2048. */
+int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
+                      fhe_mem mem, fhe_tggsw_key **out);
+void fhe_tggsw_key_destroy(fhe_tggsw_key *key);
+/* scheme/tfhe/src/tggsw.rs:100-112 `Tggsw::external_product(param, key[index], ct)`, in place on [batch][n] a / b. */
+int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, uint64_t *ct_a, uint64_t *ct_b,
+                               size_t batch, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/bootstrapping.rs:99-104 `mod_switch`: rounding_shr(v, 64 - log2(2 big_n)) for `count` torus values. */
+int fhe_tfhe_mod_switch(const uint64_t *in, uint64_t *out, size_t count, size_t big_n, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/bootstrapping.rs:84-96 `blind_rotate`: n_lwe CMUXes (tggsw.rs:114-121) per ciphertext.  a_tilde
+ * [batch][n_lwe], b_tilde [batch]: mod-switched TLWE ciphertexts; v [n]: the encoded test polynomial; out [batch][n]. */
+int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, const uint64_t *a_tilde, const uint64_t *b_tilde,
+                          const uint64_t *v, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tglwe.rs:115-127 `Tglwe::sample_extract(ct, index)`. */
+int fhe_tglwe_sample_extract(const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t *out_a, uint64_t *out_b,
+                             size_t batch, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tlwe.rs:144-153 `Tlwe::key_switch`: ksk_a [n_in*d][n_out], ksk_b [n_in*d], rows digit-major. */
+int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a, const uint64_t *ct_b,
+                        size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,4 +6,5 @@ it loads the library with ctypes and fails loudly if it is missing -- there is n
 """
 from ._lib import FheError, build, lib, lib_path  # noqa: F401
 from .ring import (BootstrapKey, CkksKey, GadgetKey, NttContext, RnsContext, automorphism,  # noqa: F401
-                   decompose, monomial_mul)
+                   decompose, monomial_mul, TorusContext, TggswKey, torus_decompose,
+                   tglwe_sample_extract, tlwe_key_switch)

@@ -93,6 +93,19 @@ def lib():
         L.fhe_ckks_key_destroy.argtypes = [vp]
         L.fhe_ckks_key_destroy.restype = None
         L.fhe_ckks_key_switch.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_torus_ctx_create.argtypes = [ci, C.POINTER(vp)]
+        L.fhe_torus_ctx_destroy.argtypes = [vp]
+        L.fhe_torus_ctx_destroy.restype = None
+        L.fhe_torus_decompose.argtypes = [ci, ci, vp, sz, sz, vp, ci, vp]
+        L.fhe_torus_mul.argtypes = [vp, vp, vp, ci, sz, sz, ci, vp]
+        L.fhe_tggsw_prepare.argtypes = [vp, ci, ci, vp, vp, sz, sz, ci, C.POINTER(vp)]
+        L.fhe_tggsw_key_destroy.argtypes = [vp]
+        L.fhe_tggsw_key_destroy.restype = None
+        L.fhe_tggsw_external_product.argtypes = [vp, vp, sz, vp, vp, sz, ci, vp]
+        L.fhe_tfhe_mod_switch.argtypes = [vp, vp, sz, sz, ci, vp]
+        L.fhe_tfhe_blind_rotate.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
+        L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         _lib = L
     return _lib
 

@@ -55,6 +55,7 @@ struct ArithShoup {
     }
     static constexpr bool GS_FOLDS = false;
     static constexpr bool JIT_TWIDDLES = true;
+    static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
@@ -157,6 +158,8 @@ struct ArithPM {
     }
     static constexpr bool GS_FOLDS = true;
     static constexpr bool JIT_TWIDDLES = true;
+    // forward layers between two folds: inputs < q + eps, a multiplicand of layer L is < (2L - 1) q and must be < 2^63
+    static constexpr int CT_LAYERS = ((1 << (63 - B)) + 1) / 2 > 64 ? 64 : ((1 << (63 - B)) + 1) / 2;
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
@@ -185,6 +188,11 @@ __device__ __forceinline__ void ct_net(u64 (&x)[E], int top, const typename A::K
         // keep the twiddle loads of a layer inside that layer: hoisting all 2^R - 1 of them to the top of the pass costs
         // more registers than the kernel has (two workgroups per CU leave 128 VGPRs per thread)
         if (A::JIT_TWIDDLES && l > 0) asm volatile("" ::: "memory");
+        // lazy policies bound how many layers may run between two folds (multiplicands must stay below 2^63)
+        if (l > 0 && l % A::CT_LAYERS == 0) {
+#pragma unroll
+            for (int r = 0; r < (1 << R); ++r) x[OFF + r] = A::fold(x[OFF + r], k);
+        }
 #pragma unroll
         for (int b = 0; b < (1 << l); ++b) {
             const int idx = (1 << (L0 + l + k.pb)) + ((((k.prefix << L0) | top)) << l) + b;

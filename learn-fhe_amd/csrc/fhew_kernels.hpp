@@ -37,7 +37,7 @@ __device__ __forceinline__ u64 decomp_next(u64 &c, const DecompParams &P) {
 }
 
 // in: [polys][n]   out: [polys][d][n] (digit-major per polynomial, least significant first)
-__global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, DecompParams P) {
+static __global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, DecompParams P) {
     const size_t total = n * polys;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -47,7 +47,7 @@ __global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ o
 }
 
 // ---- automorphism X -> X^t (util/src/avec.rs:34-50) and monomial multiply (util/src/ring.rs:299-313) ----
-__global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned t, u64 q) {
+static __global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned t, u64 q) {
     const size_t total = size_t(n) * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n;
@@ -59,7 +59,7 @@ __global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict_
     }
 }
 
-__global__ void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned k2n, u64 q) {
+static __global__ void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned k2n, u64 q) {
     const size_t total = size_t(n) * batch;
     const unsigned r = k2n & (n - 1);
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void gadget_product_kern
 
 // evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout
 template <int LOG_N>
-__global__ void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
+static __global__ void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
     constexpr int N = 1 << LOG_N;
     const size_t total = rows * N;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -254,7 +254,7 @@ constexpr unsigned BR_OP_AK = 0x80000000u;
 
 // One thread per ciphertext restates i_minus_i_plus + the walk of blind_rotate_core into an op list.
 // dlog[x] for x in [0, 2N): (l << 1) | sign (sign 1 = "minus" map), 0xffffffff if x is not +-5^l (even x)
-__global__ void blind_rotate_schedule_kernel(const u64 *__restrict__ lwe_a, unsigned n_lwe, unsigned batch, unsigned n, unsigned w,
+static __global__ void blind_rotate_schedule_kernel(const u64 *__restrict__ lwe_a, unsigned n_lwe, unsigned batch, unsigned n, unsigned w,
                                              const unsigned *__restrict__ dlog, unsigned *__restrict__ ops, unsigned *__restrict__ nops,
                                              unsigned max_ops, unsigned *__restrict__ scratch /* [batch][2 * n_lwe + n + 2] */,
                                              int *__restrict__ err) {

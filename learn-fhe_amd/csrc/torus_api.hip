@@ -1,0 +1,329 @@
+// extern "C" entry points for SURVEY.md section 8(a) row T: the TFHE torus path, k = 1.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "api_common.hpp"
+#include "ctx.hpp"
+#include "torus_kernels.hpp"
+
+struct fhe_torus_ctx {
+    int device = -1;
+    fhe_ctx *mods[2] = {nullptr, nullptr};
+    fhe::ModDesc *d_descs = nullptr;  // [2]
+    fhe::TorusConsts T{};
+};
+
+struct fhe_tggsw_key {
+    const fhe_torus_ctx *t = nullptr;
+    int log_n = 0, log_b = 0, d = 0;
+    size_t count = 0;
+    u64 *d_rows[2] = {nullptr, nullptr};  // per prime: [count][2d][2][N] evaluation domain, key_perm layout
+    fhe::TDecomp P{};
+};
+
+namespace {
+
+// the two largest pseudo-Mersenne primes of two_adic_primes(60, 16): rings up to N = 2^15
+constexpr uint64_t TORUS_P0 = 1152921504606584833ull, TORUS_P1 = 1152921504598720513ull;
+
+int make_tdecomp(int log_b, int d, fhe::TDecomp *P) {
+    if (log_b < 1 || log_b > 63 || d < 1 || d > 64) return FHE_ERR_INVALID;
+    const int rb = 64 - log_b * d > 0 ? 64 - log_b * d : 0;
+    if (rb >= 64) return FHE_ERR_INVALID;
+    P->rnd = (uint64_t(1) << rb) >> 1;
+    P->mask = (uint64_t(1) << log_b) - 1;
+    P->log_b = log_b;
+    P->d = d;
+    P->rb = rb;
+    return FHE_OK;
+}
+
+inline unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
+}
+
+#define TORUS_DISPATCH(log_n, ...)                                         \
+    switch (log_n) {                                                       \
+        case 8: { constexpr int LN = 8; __VA_ARGS__; break; }              \
+        case 9: { constexpr int LN = 9; __VA_ARGS__; break; }              \
+        case 10: { constexpr int LN = 10; __VA_ARGS__; break; }            \
+        case 11: { constexpr int LN = 11; __VA_ARGS__; break; }            \
+        default: return FHE_ERR_UNSUPPORTED;                               \
+    }
+
+int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, u64 *a, u64 *b, size_t batch, const u64 *rot,
+                size_t rot_stride, u64 *scratch, hipStream_t st) {
+    const size_t n = size_t(1) << key->log_n;
+    const size_t per = size_t(2 * key->d) * 2 * n;
+    const u64 *rows0 = key->d_rows[0] + index * per, *rows1 = key->d_rows[1] + index * per;
+    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
+    TORUS_DISPATCH(key->log_n, {
+        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_cmux_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, a, b, (unsigned)batch, rows0,
+                           rows1, key->P, rot, rot_stride, t->T, scratch);
+    });
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fhe_torus_ctx_destroy(fhe_torus_ctx *t) {
+    if (!t) return;
+    if (t->device >= 0) {
+        DeviceGuard guard(t->device);
+        if (t->d_descs) (void)hipFree(t->d_descs);
+    }
+    fhe_ctx_destroy(t->mods[0]);
+    fhe_ctx_destroy(t->mods[1]);
+    delete t;
+}
+
+int fhe_torus_ctx_create(int device, fhe_torus_ctx **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (device < 0) return FHE_ERR_NO_DEVICE;
+    fhe_torus_ctx *t = new (std::nothrow) fhe_torus_ctx();
+    if (!t) return FHE_ERR_INVALID;
+    t->device = device;
+    int rc = fhe_ctx_create(TORUS_P0, device, &t->mods[0]);
+    if (rc == FHE_OK) rc = fhe_ctx_create(TORUS_P1, device, &t->mods[1]);
+    if (rc != FHE_OK || t->mods[0]->pm_b != 60 || t->mods[1]->pm_b != 60) { fhe_torus_ctx_destroy(t); return rc != FHE_OK ? rc : FHE_ERR_UNSUPPORTED; }
+    DeviceGuard guard(device);
+    if (!guard.ok) { fhe_torus_ctx_destroy(t); return FHE_ERR_HIP; }
+    fhe::ModDesc descs[2] = {t->mods[0]->h_desc, t->mods[1]->h_desc};
+    hipError_t e = hipMalloc((void **)&t->d_descs, sizeof(descs));
+    if (e == hipSuccess) e = hipMemcpy(t->d_descs, descs, sizeof(descs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { g_last_hip = (int)e; fhe_torus_ctx_destroy(t); return FHE_ERR_HIP; }
+    const fhe::u128 P = (fhe::u128)TORUS_P0 * TORUS_P1, Ph = P >> 1;
+    t->T.descs = t->d_descs;
+    t->T.p0 = TORUS_P0; t->T.p1 = TORUS_P1;
+    t->T.inv01 = fhe::invmod(TORUS_P0 % TORUS_P1, TORUS_P1);
+    t->T.inv01_s = fhe::shoup(t->T.inv01, TORUS_P1);
+    t->T.P_lo = (uint64_t)P;
+    t->T.Ph_hi = (uint64_t)(Ph >> 64); t->T.Ph_lo = (uint64_t)Ph;
+    t->T.B0 = t->mods[0]->barrett; t->T.B1 = t->mods[1]->barrett;
+    *out = t;
+    return FHE_OK;
+}
+
+int fhe_torus_decompose(int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream) {
+    fhe::TDecomp P;
+    int rc = make_tdecomp(log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    if ((!in || !out) && n * polys) return FHE_ERR_INVALID;
+    if (n * polys == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, n * polys, mem, true, st), mo(out, n * polys * d, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::torus_decompose_kernel, dim3(grid_for(n * polys)), dim3(256), 0, st, mi.d, mo.d, n, polys, P);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// exact a <- a * b in Z_{2^64}[X]/(X^n+1) (util/src/ring.rs:315-320 `Rt *= &Rt`), operands read as signed 64-bit integers;
+// log_bound_b: |b_i| < 2^log_bound_b.  Exactness needs n * 2^(63 + log_bound_b) < p0 p1 / 2.
+int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int log_bound_b, size_t n, size_t batch, fhe_mem mem,
+                  void *stream) {
+    if (!t || !is_pow2(n) || ((!a || !b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const int log_n = ilog2(n);
+    if (log_n > 15 || log_n < 1) return FHE_ERR_UNSUPPORTED;
+    if (log_bound_b < 0 || 63 + log_bound_b + log_n + 1 > 118) return FHE_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror ma(a, n * batch, mem, true, st), mb(b, n * batch, mem, true, st);
+    if (ma.rc | mb.rc) return FHE_ERR_HIP;
+    u64 *ws = nullptr;
+    HIP_TRY(hipMalloc((void **)&ws, 4 * n * batch * sizeof(u64)));
+    u64 *ra = ws, *rb = ws + 2 * n * batch;
+    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, ra, n, batch, t->T.p0, t->T.p1);
+    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)mb.d, rb, n, batch, t->T.p0, t->T.p1);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(t->d_descs, 2, ra, log_n, 4 * batch, st, 60);  // ra and rb are adjacent
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_pointwise_kernel, dim3(grid_for(2 * n * batch)), dim3(256), 0, st, ra, (const u64 *)rb, n, batch, t->T.B0,
+                           t->T.B1);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = fhe::ntt_inv_multi(t->d_descs, 2, ra, log_n, 2 * batch, st, 60);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_crt_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ra, ma.d, n, batch, t->T);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(ws);
+    return rc;
+}
+
+void fhe_tggsw_key_destroy(fhe_tggsw_key *k) {
+    if (!k) return;
+    if (k->t && k->t->device >= 0) {
+        DeviceGuard guard(k->t->device);
+        if (k->d_rows[0]) (void)hipFree(k->d_rows[0]);
+    }
+    delete k;
+}
+
+// `count` TGGSW ciphertexts with k = 1 (scheme/tfhe/src/tggsw.rs:44-88): rows_a / rows_b = the a / b polynomials of the 2d
+// TGLWE rows of each, [count][2d][n] torus values.
+int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
+                      fhe_mem mem, fhe_tggsw_key **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!t || !rows_a || !rows_b || !is_pow2(n) || count == 0) return FHE_ERR_INVALID;
+    const int log_n = ilog2(n);
+    if (log_n < 8 || log_n > 11) return FHE_ERR_UNSUPPORTED;
+    fhe::TDecomp P;
+    int rc = make_tdecomp(log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    // exactness of the two-prime product: 2d * N * 2^(62 + log_b) < p0 p1 / 2 ~ 2^118.9
+    if (ilog2((size_t)2 * d) + 1 + log_n + 62 + log_b > 118) return FHE_ERR_UNSUPPORTED;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * 2 * d, words = rows * n;
+    hipStream_t st = nullptr;
+    u64 *src = nullptr, *tmp = nullptr, *dst = nullptr;
+    HIP_TRY(hipMalloc((void **)&src, 2 * words * sizeof(u64)));
+    hipError_t e = hipMalloc((void **)&tmp, 2 * words * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&dst, 4 * words * sizeof(u64));  // both primes
+    hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (e == hipSuccess) e = hipMemcpyAsync(src, rows_a, words * sizeof(u64), kind, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(src + words, rows_b, words * sizeof(u64), kind, st);
+    rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (e != hipSuccess) g_last_hip = (int)e;
+    for (int pi = 0; pi < 2 && rc == FHE_OK; ++pi) {
+        hipLaunchKernelGGL(fhe::torus_residue_kernel, dim3(grid_for(2 * words)), dim3(256), 0, st, (const u64 *)src, tmp, 2 * words,
+                           pi ? t->T.p1 : t->T.p0);
+        if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
+        rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
+        if (rc != FHE_OK) break;
+        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
+                                                 (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows));
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(src);
+    if (tmp) (void)hipFree(tmp);
+    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); return rc; }
+    fhe_tggsw_key *k = new (std::nothrow) fhe_tggsw_key();
+    if (!k) { (void)hipFree(dst); return FHE_ERR_INVALID; }
+    k->t = t; k->log_n = log_n; k->log_b = log_b; k->d = d; k->count = count; k->P = P;
+    k->d_rows[0] = dst; k->d_rows[1] = dst + 2 * words;
+    *out = k;
+    return FHE_OK;
+}
+
+// scheme/tfhe/src/tggsw.rs:100-112 `Tggsw::external_product(param, key[index], ct)`, in place on [batch][n] a / b
+int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, uint64_t *ct_a, uint64_t *ct_b, size_t batch,
+                               fhe_mem mem, void *stream) {
+    if (!t || !key || key->t != t || index >= key->count || ((!ct_a || !ct_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << key->log_n;
+    Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
+    if (ma.rc | mb.rc) return FHE_ERR_HIP;
+    u64 *scratch = nullptr;
+    HIP_TRY(hipMalloc((void **)&scratch, 4 * n * batch * sizeof(u64)));
+    int rc = launch_cmux(t, key, index, ma.d, mb.d, batch, nullptr, 0, scratch, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(scratch);
+    return rc;
+}
+
+// scheme/tfhe/src/bootstrapping.rs:99-104 `mod_switch`: v -> rounding_shr(v, 64 - log2(2 big_n)) for `count` torus values
+int fhe_tfhe_mod_switch(const uint64_t *in, uint64_t *out, size_t count, size_t big_n, fhe_mem mem, void *stream) {
+    if (!is_pow2(big_n) || ((!in || !out) && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    const int bits = 64 - (ilog2(big_n) + 1);
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, count, mem, true, st), mo(out, count, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::torus_rounding_shr_kernel, dim3(grid_for(count)), dim3(256), 0, st, (const u64 *)mi.d, mo.d, count, bits);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/tfhe/src/bootstrapping.rs:84-96 `blind_rotate` for a batch (k = 1): brk = key (n_lwe TGGSW ciphertexts);
+// a_tilde [batch][n_lwe], b_tilde [batch]: the mod-switched TLWE ciphertexts (values mod 2N); v: the ENCODED test polynomial
+// (Tglwe::encode(v), [n] torus values, shared by the batch); out_a, out_b [batch][n].
+int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, const uint64_t *a_tilde, const uint64_t *b_tilde,
+                          const uint64_t *v, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    if (!t || !brk || brk->t != t || ((!a_tilde || !b_tilde || !v || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << brk->log_n, n_lwe = brk->count;
+    Mirror ma(a_tilde, n_lwe * batch, mem, true, st), mb(b_tilde, batch, mem, true, st), mv(v, n, mem, true, st);
+    Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
+    if (ma.rc | mb.rc | mv.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    u64 *scratch = nullptr;
+    HIP_TRY(hipMalloc((void **)&scratch, 4 * n * batch * sizeof(u64)));
+    // acc = (0, v).rotate(-b)   (bootstrapping.rs:91-93)
+    int rc = hipMemsetAsync(moa.d, 0, n * batch * sizeof(u64), st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_monomial_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)mv.d, size_t(0), mob.d, (unsigned)n,
+                           batch, (const u64 *)mb.d, size_t(1), 1);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    // fold cmux(brk_i, acc, acc.rotate(a_i))   (94-95)
+    for (size_t i = 0; i < n_lwe && rc == FHE_OK; ++i) rc = launch_cmux(t, brk, i, moa.d, mob.d, batch, ma.d + i, n_lwe, scratch, st);
+    if (rc == FHE_OK) rc = moa.sync_out(st);
+    if (rc == FHE_OK) rc = mob.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(scratch);
+    return rc;
+}
+
+// scheme/tfhe/src/tglwe.rs:115-127 `sample_extract(ct, i)` (k = 1): ct_a, ct_b [batch][n] -> TLWE (out_a [batch][n], out_b [batch])
+int fhe_tglwe_sample_extract(const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t *out_a, uint64_t *out_b,
+                             size_t batch, fhe_mem mem, void *stream) {
+    if (!is_pow2(n) || index >= n || n > (1u << 30) || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st), moa(out_a, n * batch, mem, false, st),
+        mob(out_b, batch, mem, false, st);
+    if (ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::tglwe_sample_extract_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
+                       (unsigned)n, batch, (unsigned)index, moa.d, mob.d);
+    HIP_TRY(hipGetLastError());
+    int rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
+// scheme/tfhe/src/tlwe.rs:144-153 `Tlwe::key_switch`: ksk_a [n_in * d][n_out], ksk_b [n_in * d] (row j * n_in + i = digit j of
+// input coefficient i); ct_a [batch][n_in], ct_b [batch] -> out_a [batch][n_out], out_b [batch]
+int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a, const uint64_t *ct_b,
+                        size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    fhe::TDecomp P;
+    int rc = make_tdecomp(log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    if (!ksk_a || !ksk_b || n_in == 0 || n_out == 0 || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = n_in * d;
+    Mirror mka(ksk_a, rows * n_out, mem, true, st), mkb(ksk_b, rows, mem, true, st), ma(ct_a, n_in * batch, mem, true, st),
+        mb(ct_b, batch, mem, true, st), moa(out_a, n_out * batch, mem, false, st), mob(out_b, batch, mem, false, st);
+    if (mka.rc | mkb.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::tlwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
+                       (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    HIP_TRY(hipGetLastError());
+    rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
+}  // extern "C"

@@ -1,0 +1,274 @@
+// Row T: TFHE torus path (util/src/torus.rs, util/src/misc/decompose.rs:66-135, util/src/ring/fft/c64.rs,
+// scheme/tfhe/src/{tggsw,tglwe,tlwe,bootstrapping}.rs), k = 1.
+//
+// The reference multiplies torus polynomials (Z_{2^64}[X]/(X^N+1)) with an f64 FFT whose low bits carry rounding
+// noise (its own test bounds it by 2^(64 + log_b + log_n - 53), c64.rs:186-208).  Here the product is EXACT: both
+// operands are read as signed 64-bit integers (exactly what to_c64_twisted does, c64.rs:23-27), the integer negacyclic
+// product is computed modulo two 60-bit NTT primes with the same wave-private transforms as the FHEW kernels, and the
+// Chinese remainder of the two residues is reduced mod 2^64.  Exact needs |coefficient| < p0 p1 / 2 ~ 2^119: true for
+// every gadget product (digits <= 2^(log_b - 1), (k+1) d N 2^(62 + log_b) < 2^119 is checked at key preparation).
+// Never less exact than the reference (SURVEY.md section 8(a) row T acceptance rule), so decode-level results agree.
+#pragma once
+#include "fhew_kernels.hpp"
+
+namespace fhe {
+
+// ---- T64 gadget decomposition (decompose.rs:66-81 `new`, 114-135) ------------------------------------------------
+struct TDecomp {
+    u64 rnd;   // (1 << rounding_bits) >> 1
+    u64 mask;  // 2^log_b - 1
+    int log_b, d, rb;
+};
+
+__device__ __forceinline__ u64 tdecomp_init(u64 v, const TDecomp &P) { return (v + P.rnd) >> P.rb; }  // rounding_shr (wrapping add)
+
+__device__ __forceinline__ u64 tdecomp_next(u64 &c, const TDecomp &P) {
+    const u64 limb = c & P.mask;
+    c >>= P.log_b;
+    const u64 carry = (((limb - 1) | c) & limb) >> (P.log_b - 1);
+    c += carry;
+    return limb - (carry << P.log_b);  // signed digit as a two's-complement u64
+}
+
+// in [polys][n] -> out [polys][d][n]
+static __global__ void torus_decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, TDecomp P) {
+    const size_t total = n * polys;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        u64 c = tdecomp_init(in[idx], P);
+        for (int j = 0; j < P.d; ++j) out[(p * P.d + j) * n + i] = tdecomp_next(c, P);
+    }
+}
+
+// signed 64-bit value -> canonical residue mod p (2^59 < p < 2^60)
+__device__ __forceinline__ u64 signed_residue(u64 v, u64 p) {
+    const bool neg = (long long)v < 0;
+    u64 m = neg ? (0 - v) : v;                 // |v| <= 2^63 < 16 p
+    m = csub(m, 8 * p); m = csub(m, 4 * p); m = csub(m, 2 * p); m = csub(m, p);
+    return (neg && m) ? p - m : m;
+}
+
+// rows [rows][n] signed torus values -> residues mod the prime of descs[prime]
+static __global__ void torus_residue_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 p) {
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
+        out[idx] = signed_residue(in[idx], p);
+}
+
+// multiplication by X^k on the torus (ring.rs:299-313, negation = wrapping_neg), per-polynomial shift:
+// k = shift[p * stride] taken mod 2n; neg_shift: use -k (acc.rotate(-b), bootstrapping.rs:93)
+static __global__ void torus_monomial_kernel(const u64 *__restrict__ in, size_t in_stride, u64 *__restrict__ out, unsigned n, size_t batch,
+                                      const u64 *__restrict__ shift, size_t stride, int neg_shift) {
+    const size_t total = size_t(n) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned j = unsigned(idx - p * n);
+        unsigned k2n = unsigned(shift[p * stride]) & (2 * n - 1);
+        if (neg_shift) k2n = (2 * n - k2n) & (2 * n - 1);
+        const unsigned pos = (j + k2n) & (2 * n - 1);
+        const u64 v = in[p * in_stride + j];
+        out[p * n + (pos & (n - 1))] = pos < n ? v : 0 - v;
+    }
+}
+
+struct TorusConsts {
+    const ModDesc *descs;     // two primes p0, p1 (pseudo-Mersenne, 60 bits)
+    u64 p0, p1;
+    u64 inv01, inv01_s;       // p0^-1 mod p1 and its Shoup companion
+    u64 P_lo;                 // (p0 p1) mod 2^64
+    u64 Ph_hi, Ph_lo;         // floor(p0 p1 / 2)
+    Barrett B0, B1;           // unused by the pseudo-Mersenne multiply-accumulate, kept for the policy interface
+};
+
+// x = r0 (mod p0), x = r1 (mod p1), |x| < p0 p1 / 2  ->  x mod 2^64
+__device__ __forceinline__ u64 crt2_mod64(u64 r0, u64 r1, const TorusConsts &T) {
+    const u64 r0m = csub(r0, T.p1);                             // p0 < 2 p1
+    const u64 diff = r1 >= r0m ? r1 - r0m : r1 + T.p1 - r0m;
+    const u64 t = csub(mul_shoup_lazy(diff, T.inv01, T.inv01_s, T.p1), T.p1);
+    const u64 lo_prod = T.p0 * t, hi_prod = __umul64hi(T.p0, t);
+    const u64 lo = lo_prod + r0;
+    const u64 hi = hi_prod + (lo < lo_prod);                    // x = r0 + p0 t in [0, p0 p1)
+    const bool upper = hi > T.Ph_hi || (hi == T.Ph_hi && lo > T.Ph_lo);
+    return upper ? lo - T.P_lo : lo;                            // centred representative, mod 2^64
+}
+
+// One gadget product pass for ONE prime: st = running digit state of (da | db); outputs the residues of
+// sum_l rows[l].a * limb_l and sum_l rows[l].b * limb_l (exact integers) mod that prime, coefficient layout.
+template <int LOG_N>
+__device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, const u64 *__restrict__ db, const u64 *__restrict__ rows,
+                                                  const TDecomp &P, u64 p, int lane, u64 *lds, const Barrett &B,
+                                                  const typename ArithPM<60>::K &k, u64 (&sa)[1 << (LOG_N - 6)],
+                                                  u64 (&sb)[1 << (LOG_N - 6)]) {
+    using A = ArithPM<60>;
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E;
+    RingConsts K;
+    K.desc = nullptr;
+    K.B = B;
+    u64 st[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = tdecomp_init(da[coef_index<LOG_N>(lane, e)], P); }
+#pragma unroll 1
+    for (int j = 0; j < 2 * P.d; ++j) {
+        if (j == P.d) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) st[e] = tdecomp_init(db[coef_index<LOG_N>(lane, e)], P);
+        }
+        u64 x[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u64 dg = tdecomp_next(st[e], P);
+            x[e] = (long long)dg < 0 ? p - (0 - dg) : dg;  // |digit| <= 2^(log_b-1) < p
+        }
+        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, k);
+        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(sa[e], k); sb[e] = A::mac_finish(sb[e], k); }
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
+    }
+}
+
+// scheme/tfhe/src/tggsw.rs:100-121 for k = 1, one wave per ciphertext.
+//   rot == nullptr: (a, b) <- external_product(key, (a, b))
+//   rot != nullptr: CMUX step of the blind rotation: (a, b) <- (a, b) + external_product(key, (a, b) X^r - (a, b)),
+//                   r = rot[ct * rot_stride] mod 2N  (acc.rotate(a_i), bootstrapping.rs:94-95)
+// scratch: [batch][4][N] u64 (difference polynomials and the first prime's residues)
+template <int LOG_N>
+__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void torus_cmux_kernel(
+    u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch, const u64 *__restrict__ rows0, const u64 *__restrict__ rows1,
+    TDecomp P, const u64 *__restrict__ rot, size_t rot_stride, TorusConsts T, u64 *__restrict__ scratch) {
+    using A = ArithPM<60>;
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E, N = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
+    u64 *da = scratch + size_t(ct) * 4 * N, *db = da + N, *r0a = db + N, *r0b = r0a + N;
+    const bool cmux = rot != nullptr;
+    unsigned r = 0;
+    if (cmux) {
+        r = unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1);
+        if (r == 0) return;  // acc X^0 - acc = 0: the external product of zero is exactly zero
+    }
+    // difference polynomials (or the ciphertext itself) -> scratch, each lane touching only its own coefficients
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const u64 *src = h ? gb : ga;
+        u64 *dst = h ? db : da;
+        u64 c[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) c[e] = src[coef_index<LOG_N>(lane, e)];
+        if (cmux) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned pos = (unsigned(coef_index<LOG_N>(lane, e)) + r) & (2 * N - 1);
+                lds[lds_phys(pos & (N - 1))] = pos < N ? c[e] : 0 - c[e];
+            }
+            exchange_sync<true>();
+#pragma unroll
+            for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))] - c[e];
+            exchange_sync<true>();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[coef_index<LOG_N>(lane, e)] = c[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // own writes, own reads: program order per lane suffices
+    u64 sa[E], sb[E];
+    {
+        const typename A::K k0 = A::make(T.descs[0], LOG_N, 0, 0);
+        wave_torus_gadget<LOG_N>(da, db, rows0, P, T.p0, lane, lds, T.B0, k0, sa, sb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { r0a[coef_index<LOG_N>(lane, e)] = sa[e]; r0b[coef_index<LOG_N>(lane, e)] = sb[e]; }
+    }
+    {
+        const typename A::K k1 = A::make(T.descs[1], LOG_N, 0, 0);
+        wave_torus_gadget<LOG_N>(da, db, rows1, P, T.p1, lane, lds, T.B1, k1, sa, sb);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = coef_index<LOG_N>(lane, e);
+        const u64 xa = crt2_mod64(r0a[i], sa[e], T), xb = crt2_mod64(r0b[i], sb[e], T);
+        ga[i] = cmux ? ga[i] + xa : xa;
+        gb[i] = cmux ? gb[i] + xb : xb;
+    }
+}
+
+// exact torus product building blocks for fhe_torus_mul: c = a * b with |b| small (two-prime CRT)
+static __global__ void torus_crt_kernel(const u64 *__restrict__ r /* [batch][2][n] */, u64 *__restrict__ out, size_t n, size_t batch, TorusConsts T) {
+    const size_t total = n * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        out[idx] = crt2_mod64(r[(p * 2) * n + i], r[(p * 2 + 1) * n + i], T);
+    }
+}
+
+// a, b [batch][n] signed torus values -> ra, rb [batch][2][n] residues
+static __global__ void torus_residue2_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t batch, u64 p0, u64 p1) {
+    const size_t total = n * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n, i = idx - p * n;
+        const u64 v = in[idx];
+        out[(p * 2) * n + i] = signed_residue(v, p0);
+        out[(p * 2 + 1) * n + i] = signed_residue(v, p1);
+    }
+}
+
+// ra <- ra (.) rb per prime; [batch][2][n]
+static __global__ void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *__restrict__ rb, size_t n, size_t batch, Barrett B0, Barrett B1) {
+    const size_t total = 2 * n * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const bool second = (idx / n) & 1;
+        ra[idx] = mulmod_barrett(ra[idx], rb[idx], second ? B1 : B0);
+    }
+}
+
+// scheme/tfhe/src/tglwe.rs:115-127 (k = 1): [batch][n] a, b -> TLWE a [batch][n], b [batch]
+static __global__ void tglwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
+                                            u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    const size_t total = size_t(n) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned j = unsigned(idx - p * n);
+        // a[..i+1].rev() ++ a[i+1..].rev().map(neg)
+        out_a[idx] = j <= i ? ct_a[p * n + (i - j)] : 0 - ct_a[p * n + (n - 1 - (j - i - 1))];
+        if (j == 0) out_b[p] = ct_b[p * n + i];
+    }
+}
+
+// scheme/tfhe/src/tlwe.rs:144-153: one thread per (ciphertext, output coefficient); ksk_a [n_in*d][n_out], ksk_b [n_in*d]
+// (row index j * n_in + i: digit-major, as `decompose(a).flatten()` orders the limbs); output index n_out carries b
+static __global__ void tlwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
+                                       size_t batch, const u64 *__restrict__ ksk_a, const u64 *__restrict__ ksk_b, TDecomp P,
+                                       u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    const size_t total = size_t(n_out + 1) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / (n_out + 1);
+        const unsigned kcol = unsigned(idx - p * (n_out + 1));
+        u64 acc = 0;
+        for (unsigned i = 0; i < n_in; ++i) {
+            u64 c = tdecomp_init(ct_a[p * n_in + i], P);
+            for (int j = 0; j < P.d; ++j) {
+                const u64 dg = tdecomp_next(c, P);
+                const size_t row = size_t(j) * n_in + i;
+                acc += (kcol < n_out ? ksk_a[row * n_out + kcol] : ksk_b[row]) * dg;  // wrapping: arithmetic mod 2^64
+            }
+        }
+        if (kcol < n_out) out_a[p * n_out + kcol] = acc;
+        else out_b[p] = acc + ct_b[p];
+    }
+}
+
+// util/src/torus-side rounding_shr used by bootstrapping.rs:99-104 `mod_switch`
+static __global__ void torus_rounding_shr_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, int bits) {
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
+        out[idx] = (in[idx] + ((u64(1) << bits) >> 1)) >> bits;
+}
+
+}  // namespace fhe

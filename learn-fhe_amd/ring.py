@@ -260,3 +260,103 @@ class CkksKey:
         pa, _, _, _ = _buf(ct_a)
         batch = cnt // (self.rns.L * self.n)
         L.check(L.lib().fhe_ckks_key_switch(self.rns.handle, self._h, pb, pa, batch, mem, st), "fhe_ckks_key_switch")
+
+
+# ---- row T: TFHE torus path ------------------------------------------------------------------------------
+
+
+def torus_decompose(log_b, d, a, n):
+    """util/src/misc/decompose.rs:114-135 on T64: [polys][n] -> [polys][d][n]."""
+    p, cnt, mem, st = _buf(a)
+    out = _like(a, (cnt // n, d, n))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_torus_decompose(log_b, d, p, n, cnt // n, po, mem, st), "fhe_torus_decompose")
+    return out
+
+
+class TorusContext:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_torus_ctx_create(device, C.byref(self._h)), "fhe_torus_ctx_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_torus_ctx_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def mul_(self, a, b, log_bound_b, n):
+        """a <- a * b in Z_{2^64}[X]/(X^n+1), exact (ring.rs:315-320)."""
+        pa, cnt, mem, st = _buf(a)
+        pb, _, _, _ = _buf(b)
+        L.check(L.lib().fhe_torus_mul(self._h, pa, pb, log_bound_b, n, cnt // n, mem, st), "fhe_torus_mul")
+        return a
+
+    @staticmethod
+    def mod_switch(v, big_n):
+        p, cnt, mem, st = _buf(v)
+        out = _like(v, tuple(v.shape))
+        po, _, _, _ = _buf(out)
+        L.check(L.lib().fhe_tfhe_mod_switch(p, po, cnt, big_n, mem, st), "fhe_tfhe_mod_switch")
+        return out
+
+
+class TggswKey:
+    """Prepared TGGSW ciphertexts, k = 1 (scheme/tfhe/src/tggsw.rs:44-88)."""
+
+    def __init__(self, t: TorusContext, log_b, d, rows_a, rows_b, n):
+        self.t, self.log_b, self.d, self.n = t, log_b, d, n
+        pa, cnt, mem, _ = _buf(rows_a)
+        pb, _, _, _ = _buf(rows_b)
+        self.count = cnt // (2 * d * n)
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_tggsw_prepare(t.handle, log_b, d, pa, pb, n, self.count, mem, C.byref(self._h)), "fhe_tggsw_prepare")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            L.lib().fhe_tggsw_key_destroy(h)
+
+    def external_product_(self, index, ct_a, ct_b):
+        pa, cnt, mem, st = _buf(ct_a)
+        pb, _, _, _ = _buf(ct_b)
+        L.check(L.lib().fhe_tggsw_external_product(self.t.handle, self._h, index, pa, pb, cnt // self.n, mem, st),
+                "fhe_tggsw_external_product")
+
+    def blind_rotate(self, a_tilde, b_tilde, v):
+        """scheme/tfhe/src/bootstrapping.rs:84-96."""
+        pa, cnt, mem, st = _buf(a_tilde)
+        pb, batch, _, _ = _buf(b_tilde)
+        pv, _, _, _ = _buf(v)
+        out_a, out_b = _like(a_tilde, (batch, self.n)), _like(a_tilde, (batch, self.n))
+        poa, _, _, _ = _buf(out_a)
+        pob, _, _, _ = _buf(out_b)
+        L.check(L.lib().fhe_tfhe_blind_rotate(self.t.handle, self._h, pa, pb, pv, poa, pob, batch, mem, st), "fhe_tfhe_blind_rotate")
+        return out_a, out_b
+
+
+def tglwe_sample_extract(ct_a, ct_b, n, index):
+    pa, cnt, mem, st = _buf(ct_a)
+    pb, _, _, _ = _buf(ct_b)
+    batch = cnt // n
+    out_a, out_b = _like(ct_a, (batch, n)), _like(ct_a, (batch,))
+    poa, _, _, _ = _buf(out_a)
+    pob, _, _, _ = _buf(out_b)
+    L.check(L.lib().fhe_tglwe_sample_extract(pa, pb, n, index, poa, pob, batch, mem, st), "fhe_tglwe_sample_extract")
+    return out_a, out_b
+
+
+def tlwe_key_switch(log_b, d, ksk_a, ksk_b, ct_a, ct_b, n_in, n_out):
+    pka, _, mem, st = _buf(ksk_a)
+    pkb, _, _, _ = _buf(ksk_b)
+    pa, cnt, _, _ = _buf(ct_a)
+    pb, _, _, _ = _buf(ct_b)
+    batch = cnt // n_in
+    out_a, out_b = _like(ct_a, (batch, n_out)), _like(ct_a, (batch,))
+    poa, _, _, _ = _buf(out_a)
+    pob, _, _, _ = _buf(out_b)
+    L.check(L.lib().fhe_tlwe_key_switch(log_b, d, pka, pkb, pa, pb, n_in, n_out, poa, pob, batch, mem, st), "fhe_tlwe_key_switch")
+    return out_a, out_b

@@ -772,3 +772,182 @@ class SplitMix64:
     def uniform(self, q, n):
         """n values in [0,q): 64-bit draw mod q (bias irrelevant for test data)."""
         return [self.next() % q for _ in range(n)]
+
+
+# --------------------------------------------------------------------------------------
+# Row T: TFHE torus path (util/src/torus.rs, misc/decompose.rs:66-135, ring/fft/c64.rs,
+# scheme/tfhe/src/{tggsw,tglwe,tlwe,bootstrapping}.rs).  T64 = integers mod 2^64 (wrapping).
+#
+# The reference multiplies torus polynomials with an f64 FFT (c64.rs:11-56) whose low bits carry
+# rounding noise; its own test bounds the error by 2^(64 + log_b + log_n - 53) (c64.rs:186-208).
+# This oracle computes the EXACT negacyclic product mod 2^64 (both operands read as signed i64,
+# exactly as to_c64_twisted does with `to_i64() as f64`, c64.rs:20-28): the reference's result is
+# within its bound of these values, never the other way round.
+# --------------------------------------------------------------------------------------
+M64 = 1 << 64
+
+
+def t64_to_i64(v):
+    return v - M64 if v >= (1 << 63) else v
+
+
+def torus_mul_exact(a, b):
+    """Z_{2^64}[X]/(X^N+1) product, operands as signed i64 (c64.rs:23-27), exact."""
+    n = len(a)
+    sa, sb = [t64_to_i64(x) for x in a], [t64_to_i64(x) for x in b]
+    c = [0] * n
+    for i, x in enumerate(sa):
+        if x == 0:
+            continue
+        for j, y in enumerate(sb):
+            if i + j < n:
+                c[i + j] += x * y
+            else:
+                c[i + j - n] -= x * y
+    return [v % M64 for v in c]
+
+
+def torus_monomial_mul(a, k):
+    """util/src/ring.rs:299-313 on Rt: negation is wrapping_neg (torus.rs:48-57)."""
+    n = len(a)
+    i = k % (2 * n)
+    r = i % n
+    out = a[n - r:] + a[:n - r] if r else list(a)
+    rng = range(i) if i < n else range(i - n, n)
+    for j in rng:
+        out[j] = (-out[j]) % M64
+    return out
+
+
+class TorusDecomposor:
+    """util/src/misc/decompose.rs:66-81 (new), 114-135 (T64: Base2Decomposable)."""
+
+    def __init__(self, log_b, d):
+        self.log_b, self.d = log_b, d
+        self.rounding_bits = max(64 - log_b * d, 0)
+        self.bases = [(1 << (self.rounding_bits + j * log_b)) % M64 for j in range(d)]
+
+    def decompose_scalar(self, v):
+        bits, log_b = self.rounding_bits, self.log_b
+        v = ((v + ((1 << bits) >> 1)) % M64) >> bits      # rounding_shr, 115-118
+        mask = (1 << log_b) - 1
+        out = []
+        for _ in range(self.d):                            # 124-134
+            limb = v & mask
+            v >>= log_b
+            carry = (((limb - 1) % M64 | v) & limb) >> (log_b - 1)
+            v = (v + carry) % M64
+            out.append((limb - (carry << log_b)) % M64)
+        return out
+
+    def decompose(self, poly):
+        digs = [self.decompose_scalar(v) for v in poly]
+        return [[digs[i][j] for i in range(len(poly))] for j in range(self.d)]
+
+    def power_up_poly(self, v):
+        return [[(base * x) % M64 for x in v] for base in self.bases]
+
+    def power_up_i64(self, v):
+        return [[(base * x) % M64 for x in v] for base in self.bases]
+
+
+def tpoly_add(a, b):
+    return [(x + y) % M64 for x, y in zip(a, b)]
+
+
+def tpoly_sub(a, b):
+    return [(x - y) % M64 for x, y in zip(a, b)]
+
+
+def tggsw_external_product(dec: TorusDecomposor, rows_a, rows_b, ct_a, ct_b):
+    """scheme/tfhe/src/tggsw.rs:100-112 for k = 1: limbs = decompose(a) ++ decompose(b);
+    a' = sum_l rows_a[l] * limb_l, b' = sum_l rows_b[l] * limb_l  (key polynomial is the lhs of each product)."""
+    limbs = dec.decompose(ct_a) + dec.decompose(ct_b)
+    n = len(ct_a)
+    oa, ob = [0] * n, [0] * n
+    for ra, rb, l in zip(rows_a, rows_b, limbs):
+        oa = tpoly_add(oa, torus_mul_exact(ra, l))
+        ob = tpoly_add(ob, torus_mul_exact(rb, l))
+    return oa, ob
+
+
+def tggsw_cmux(dec, rows_a, rows_b, ct0, ct1):
+    """scheme/tfhe/src/tggsw.rs:114-121: ct0 + external_product(b, ct1 - ct0)."""
+    da, db = tpoly_sub(ct1[0], ct0[0]), tpoly_sub(ct1[1], ct0[1])
+    ea, eb = tggsw_external_product(dec, rows_a, rows_b, da, db)
+    return tpoly_add(ct0[0], ea), tpoly_add(ct0[1], eb)
+
+
+def tfhe_mod_switch(values, big_n):
+    """scheme/tfhe/src/bootstrapping.rs:99-104: rounding_shr(64 - log2(2N)) -> i64."""
+    bits = 64 - (2 * big_n).bit_length() + 1
+    return [(((v + ((1 << bits) >> 1)) % M64) >> bits) for v in values]
+
+
+def tfhe_blind_rotate(dec, brk, v_encoded, a_tilde, b_tilde):
+    """scheme/tfhe/src/bootstrapping.rs:84-96 for k = 1: acc = (0, v).rotate(-b); fold cmux(brk_i, acc, acc.rotate(a_i))."""
+    n = len(v_encoded)
+    acc = ([0] * n, torus_monomial_mul(v_encoded, -b_tilde))
+    for (ra, rb), ai in zip(brk, a_tilde):
+        rot = (torus_monomial_mul(acc[0], ai), torus_monomial_mul(acc[1], ai))
+        acc = tggsw_cmux(dec, ra, rb, acc, rot)
+    return acc
+
+
+def tglwe_sample_extract(ct_a, ct_b, i):
+    """scheme/tfhe/src/tglwe.rs:115-127 (k = 1)."""
+    a = list(reversed(ct_a[: i + 1])) + [(-v) % M64 for v in reversed(ct_a[i + 1:])]
+    return a, ct_b[i]
+
+
+def tlwe_key_switch(dec: TorusDecomposor, ksk_a, ksk_b, ct_a, ct_b):
+    """scheme/tfhe/src/tlwe.rs:144-153: limbs digit-major (decompose(a).flatten())."""
+    limbs = [x for poly in dec.decompose(ct_a) for x in poly]
+    n_out = len(ksk_a[0])
+    a = [0] * n_out
+    b = 0
+    for ra, rb, l in zip(ksk_a, ksk_b, limbs):
+        for k in range(n_out):
+            a[k] = (a[k] + ra[k] * l) % M64
+        b = (b + rb * l) % M64
+    return a, (b + ct_b) % M64
+
+
+# ---- key material for decode-level tests (noise-free or tiny noise; sampling is not parity relevant) ----
+
+def tglwe_sk_encrypt(s_bits, pt, rng, noise=0):
+    """scheme/tfhe/src/tglwe.rs:89-101 (k = 1): b = a * s + e + pt."""
+    n = len(pt)
+    a = [rng.getrandbits(64) for _ in range(n)]
+    e = [rng.randint(-noise, noise) % M64 if noise else 0 for _ in range(n)]
+    s = [x % M64 for x in s_bits]
+    return a, tpoly_add(tpoly_add(torus_mul_exact(a, s), e), pt)
+
+
+def tggsw_sk_encrypt(dec, s_bits, pt, rng, noise=0):
+    """scheme/tfhe/src/tggsw.rs:73-88 (k = 1): 2d TGLWE zeros; rows 0..d get pt*base on a, d..2d on b."""
+    n, d = len(pt), dec.d
+    pts = dec.power_up_poly(pt)
+    rows = [tglwe_sk_encrypt(s_bits, [0] * n, rng, noise) for _ in range(2 * d)]
+    ra, rb = [r[0] for r in rows], [r[1] for r in rows]
+    for j in range(d):
+        ra[j] = tpoly_add(ra[j], pts[j])
+        rb[d + j] = tpoly_add(rb[d + j], pts[j])
+    return ra, rb
+
+
+def tlwe_sk_encrypt(sk, pt, rng, noise=0):
+    """scheme/tfhe/src/tlwe.rs:120-131."""
+    a = [rng.getrandbits(64) for _ in sk]
+    e = rng.randint(-noise, noise) if noise else 0
+    return a, (sum(x * s for x, s in zip(a, sk)) + e + pt) % M64
+
+
+def tlwe_ksk_gen(dec, sk0, sk1, rng, noise=0):
+    """scheme/tfhe/src/tlwe.rs:98-109: rows encrypt (-sk1_i) * base_j under sk0, digit-major."""
+    rows = [tlwe_sk_encrypt(sk0, pt, rng, noise) for poly in dec.power_up_i64([-s for s in sk1]) for pt in poly]
+    return [r[0] for r in rows], [r[1] for r in rows]
+
+
+def tlwe_phase(sk, a, b):
+    return (b - sum(x * s for x, s in zip(a, sk))) % M64

@@ -95,7 +95,8 @@ def test_gadget_products_golden(fhe, torch_cuda):
         rgsw.key_switch_(0, dev(torch_cuda, U(v["ct_a"])), dev(torch_cuda, U(v["ct_b"])))
 
 
-@pytest.mark.parametrize("log_n,bits,log_b,d", [(7, 45, 5, 9), (8, 28, 7, 4), (9, 28, 7, 4), (10, 54, 6, 9), (11, 55, 11, 5)])
+@pytest.mark.parametrize("log_n,bits,log_b,d", [(7, 45, 5, 9), (8, 28, 7, 4), (9, 28, 7, 4), (9, 54, 6, 9), (10, 54, 6, 9), (11, 55, 11, 5),
+                                                (11, 54, 9, 6)])
 def test_gadget_products_vs_oracle(fhe, cref, torch_cuda, log_n, bits, log_b, d):
     """reference parameter sets (rgsw.rs:164-227 (5,9)@45; boolean.rs:225-239 (7,4)@28; cfg3 (6,9)@54; example (11,5)@55);
     uniform-random key rows, ragged batch, two key entries"""

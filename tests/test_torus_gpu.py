@@ -1,0 +1,187 @@
+"""GPU parity tests for SURVEY.md section 8(a) row T (TFHE torus path, k = 1) through the C ABI.
+Acceptance rule of row T: (i) decode-level equality, (ii) per-coefficient distance to the exact negacyclic product mod 2^64
+within the reference's own bound (util/src/ring/fft/c64.rs:186-208).  The GPU path is exact, so (ii) is asserted as
+equality with the exact oracle (oracle/pyref.py), which is inside the reference's bound by definition."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = lambda x: [int(v) for v in np.asarray(x).ravel()]  # noqa: E731
+U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_torus_decompose(fhe, torch_cuda):
+    from oracle import pyref as P
+    rnd = random.Random(1)
+    for log_b, d in [(23, 1), (4, 5), (8, 3), (16, 4), (7, 9), (32, 2)]:
+        dec = P.TorusDecomposor(log_b, d)
+        v = [0, 1, P.M64 - 1, 1 << 63, (1 << 63) - 1, (1 << 40) - 1] + [rnd.getrandbits(64) for _ in range(58)]
+        out = host(fhe.torus_decompose(log_b, d, dev(torch_cuda, U(v)), len(v)))
+        assert out.reshape(d, len(v)).tolist() == dec.decompose(v)
+
+
+@pytest.mark.parametrize("n", [2, 64, 1024, 4096])
+def test_torus_mul_exact(fhe, torch_cuda, n):
+    """`Rt * Rt` (ring.rs:315-320): exact product, hence within the reference's precision bound (c64.rs:186-208) for the
+    operand sizes that test uses (b up to 2^17)"""
+    from oracle import pyref as P
+    rnd = random.Random(n)
+    t = fhe.TorusContext()
+    for log_bound in (1, 12, 17, 23):
+        a = [rnd.getrandbits(64) for _ in range(n)]
+        b = [rnd.randint(-(1 << log_bound) + 1, (1 << log_bound) - 1) % P.M64 for _ in range(n)]
+        da, db = dev(torch_cuda, U(a)), dev(torch_cuda, U(b))
+        t.mul_(da, db, log_bound, n)
+        if n <= 1024:
+            assert L(host(da)) == P.torus_mul_exact(a, b), (n, log_bound)
+        else:  # full schoolbook is slow in Python: check 8 output coefficients
+            sa, sb = [P.t64_to_i64(x) for x in a], [P.t64_to_i64(x) for x in b]
+            got = host(da)
+            for k in (0, 1, n // 2, n - 1, 17, 1000, 2049, 4000):
+                exp = sum(sa[i] * sb[k - i] for i in range(k + 1)) - sum(sa[i] * sb[n + k - i] for i in range(k + 1, n))
+                assert int(got[k]) == exp % P.M64
+
+
+def test_tggsw_external_product_vs_oracle(fhe, torch_cuda):
+    """uniform-random TGGSW rows (validity is irrelevant for parity), N = 256, three gadget shapes, batch 3"""
+    from oracle import pyref as P
+    rnd = random.Random(7)
+    n, batch = 256, 3
+    t = fhe.TorusContext()
+    for log_b, d in [(23, 1), (8, 3), (4, 5)]:
+        dec = P.TorusDecomposor(log_b, d)
+        ra = [[[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)] for _ in range(2)]
+        rb = [[[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)] for _ in range(2)]
+        key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, U(ra)), dev(torch_cuda, U(rb)), n)
+        ca = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(batch)]
+        cb = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(batch)]
+        ca[0][:3] = [0, P.M64 - 1, 1 << 63]
+        for idx in range(2):
+            a, b = dev(torch_cuda, U(ca)), dev(torch_cuda, U(cb))
+            key.external_product_(idx, a, b)
+            for i in range(batch):
+                ea, eb = P.tggsw_external_product(dec, ra[idx], rb[idx], ca[i], cb[i])
+                assert L(host(a)[i]) == ea and L(host(b)[i]) == eb, (log_b, d, idx, i)
+
+
+def test_tggsw_external_product_n2048(fhe, torch_cuda):
+    """the reference's ring (big_n = 2048, log_b = 23, d = 1): one external product, bit-exact against the exact oracle"""
+    from oracle import pyref as P
+    rnd = random.Random(8)
+    n, log_b, d = 2048, 23, 1
+    dec = P.TorusDecomposor(log_b, d)
+    t = fhe.TorusContext()
+    ra = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)]
+    rb = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)]
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, U([ra])), dev(torch_cuda, U([rb])), n)
+    ca, cb = [rnd.getrandbits(64) for _ in range(n)], [rnd.getrandbits(64) for _ in range(n)]
+    a, b = dev(torch_cuda, U([ca])), dev(torch_cuda, U([cb]))
+    key.external_product_(0, a, b)
+    ea, eb = P.tggsw_external_product(dec, ra, rb, ca, cb)
+    assert L(host(a)) == ea and L(host(b)) == eb
+
+
+def test_blind_rotate_and_gate_vs_oracle(fhe, torch_cuda):
+    """N = 256, n_lwe = 6: CMUX chain, sample extract and TLWE key switch bit-exact against the exact oracle"""
+    from oracle import pyref as P
+    rnd = random.Random(9)
+    n, n_lwe, batch, log_b, d = 256, 6, 3, 10, 2
+    dec, ksdec = P.TorusDecomposor(log_b, d), P.TorusDecomposor(4, 5)
+    t = fhe.TorusContext()
+    brk = [([[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)], [[rnd.getrandbits(64) for _ in range(n)] for _ in range(2 * d)])
+           for _ in range(n_lwe)]
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, U([k[0] for k in brk])), dev(torch_cuda, U([k[1] for k in brk])), n)
+    v = [rnd.getrandbits(64) for _ in range(n)]
+    a_raw = [[rnd.getrandbits(64) for _ in range(n_lwe)] for _ in range(batch)]
+    b_raw = [rnd.getrandbits(64) for _ in range(batch)]
+    a_raw[1][2] = 0  # rotation by zero: the CMUX leaves the accumulator untouched
+    at = host(fhe.TorusContext.mod_switch(dev(torch_cuda, U(a_raw)), n))
+    bt = host(fhe.TorusContext.mod_switch(dev(torch_cuda, U(b_raw)), n))
+    for i in range(batch):
+        assert L(at[i]) == P.tfhe_mod_switch(a_raw[i], n)
+    assert L(bt) == P.tfhe_mod_switch(b_raw, n)
+    oa, ob = key.blind_rotate(dev(torch_cuda, at), dev(torch_cuda, bt), dev(torch_cuda, U(v)))
+    ksa = [[rnd.getrandbits(64) for _ in range(n_lwe)] for _ in range(n * 5)]
+    ksb = [rnd.getrandbits(64) for _ in range(n * 5)]
+    ea, eb = fhe.tglwe_sample_extract(oa, ob, n, 0)
+    ka, kb = fhe.tlwe_key_switch(4, 5, dev(torch_cuda, U(ksa)), dev(torch_cuda, U(ksb)), ea, eb, n, n_lwe)
+    for i in range(batch):
+        acc = P.tfhe_blind_rotate(dec, brk, v, L(at[i]), int(bt[i]))
+        assert L(host(oa)[i]) == acc[0] and L(host(ob)[i]) == acc[1], i
+        xa, xb = P.tglwe_sample_extract(acc[0], acc[1], 0)
+        assert L(host(ea)[i]) == xa and int(host(eb)[i]) == xb
+        ya, yb = P.tlwe_key_switch(ksdec, ksa, ksb, xa, xb)
+        assert L(host(ka)[i]) == ya and int(host(kb)[i]) == yb
+    xa7, xb7 = fhe.tglwe_sample_extract(oa, ob, n, 7)
+    assert (L(host(xa7)[0]), int(host(xb7)[0])) == P.tglwe_sample_extract(L(host(oa)[0]), L(host(ob)[0]), 7)
+
+
+def test_gate_bootstrap_decode_level_reference_parameters(fhe, torch_cuda):
+    """scheme/tfhe/src/bootstrapping.rs:139-165 on the GPU path, the reference's only parameter set: big_n = 2048, k = 1,
+    log_b = 23, d = 1, n_lwe = 1024 (binary key), key switch (4, 5), log_p = 4, padding 1; LUTs identity / double / parity
+    over all 16 messages in ONE batch of 48 ciphertexts.  Keys come from the oracle's key generator (noise as wide as the
+    reference's tdg draws would be, a few units of the last place at these standard deviations)."""
+    from oracle import pyref as P
+    rnd = random.Random(11)
+    n, n_lwe, log_p, padding, log_b, d = 2048, 1024, 4, 1, 23, 1
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    dec, ksdec = P.TorusDecomposor(log_b, d), P.TorusDecomposor(4, 5)
+    z = [rnd.randint(0, 1) for _ in range(n_lwe)]
+    s = [rnd.randint(0, 1) for _ in range(n)]
+    t = fhe.TorusContext()
+    # TGGSW(z_i) under s: rows = TGLWE zeros + z_i * base on a (rows 0..d) / on b (rows d..2d).  Encryptions of zero are
+    # built with the exact GPU product (b = a * s + e): one batched torus_mul instead of n_lwe * 2d Python schoolbooks.
+    rows = n_lwe * 2 * d
+    rng = np.random.Generator(np.random.PCG64(5))
+    A = rng.integers(0, 1 << 63, size=(rows, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(rows, n), dtype=np.uint64)
+    S = np.tile(np.array(s, dtype=np.uint64), (rows, 1))
+    dB = dev(torch_cuda, A.copy())
+    t.mul_(dB, dev(torch_cuda, S), 1, n)
+    Bm = host(dB) + rng.integers(0, 5, size=(rows, n), dtype=np.uint64) - np.uint64(2)  # e in [-2, 2]
+    ra, rb = A.reshape(n_lwe, 2 * d, n).copy(), Bm.reshape(n_lwe, 2 * d, n).copy()
+    for i, zi in enumerate(z):
+        for j, base in enumerate(dec.bases):
+            ra[i, j, 0] += np.uint64(zi * base % P.M64)
+            rb[i, d + j, 0] += np.uint64(zi * base % P.M64)
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+    ksa, ksb = P.tlwe_ksk_gen(ksdec, z, s, rnd, noise=2)
+
+    def table(f):
+        m_ = n >> log_p
+        tt = [f(v) % p for v in range(p)]
+        out = [tt[0]] * (m_ // 2)
+        for x in tt[1:]:
+            out += [x] * m_
+        return out + [(-tt[0]) % p] * (m_ // 2)
+
+    luts = [lambda v: v, lambda v: 2 * v, lambda v: v % 2]
+    for f in luts:
+        v = [(x << log_delta) % P.M64 for x in table(f)]
+        cts = [P.tlwe_sk_encrypt(z, (m << log_delta) % P.M64, rnd, noise=2) for m in range(p)]
+        a_raw, b_raw = U([c[0] for c in cts]), U([c[1] for c in cts])
+        at = fhe.TorusContext.mod_switch(dev(torch_cuda, a_raw), n)
+        bt = fhe.TorusContext.mod_switch(dev(torch_cuda, b_raw), n)
+        oa, ob = key.blind_rotate(at, bt, dev(torch_cuda, U(v)))
+        ea, eb = fhe.tglwe_sample_extract(oa, ob, n, 0)
+        ka, kb = fhe.tlwe_key_switch(4, 5, dev(torch_cuda, U(ksa)), dev(torch_cuda, U(ksb)), ea, eb, n, n_lwe)
+        for m in range(p):
+            mu = ((P.tlwe_phase(z, L(host(ka)[m]), int(host(kb)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
+            assert mu % p == f(m) % p, (m, mu)
