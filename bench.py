@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the final all_gather of results (not in value)")
     ap.add_argument("--no-fhew", action="store_true", help="skip the secondary FHEW blind-rotation figures")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the control path)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (only meaningful with --dist-backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -121,11 +125,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -163,7 +172,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
@@ -174,7 +183,7 @@ def main():
         from learn_fhe_amd.shard import gather_results
         barrier()
         t0 = time.perf_counter()
-        gather_results(a)
+        gather_results(a if args.dist_backend == "nccl" else a.cpu())
         barrier()
         gather_ms = (time.perf_counter() - t0) * 1e3
 
@@ -191,7 +200,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<ArithPM<60>,14,4,1> (forward transform)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
+                         "traffic": load_traffic() if args.batch == BATCH else None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
                          "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9},
         }
