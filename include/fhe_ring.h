@@ -126,6 +126,29 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
                      size_t f_stride, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream,
                      uint32_t *ops_out, uint32_t *nops_out);
 
+/* ---- the LWE side of the FHEW gate ------------------------------------------- */
+/* util/src/zq.rs:128-140 via scheme/fhew/src/lwe.rs:90-99: `mod_switch(q_prime)` (odd = 0) / `mod_switch_odd` (odd != 0)
+ * for `count` values over q: the reference's f64 arithmetic and rounding reproduced with IEEE double operations. */
+int fhe_lwe_mod_switch(uint64_t q, uint64_t q_prime, const uint64_t *in, uint64_t *out, size_t count, int odd, fhe_mem mem,
+                       void *stream);
+/* scheme/fhew/src/lwe.rs:151-160 `Lwe::key_switch` over q < 2^32: ksk_a [d*n_in][n_out], ksk_b [d*n_in], rows digit-major. */
+int fhe_lwe_key_switch(uint64_t q, int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a,
+                       const uint64_t *ct_b, size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
+                       void *stream);
+/* scheme/fhew/src/lwe.rs:22-75 (Add / Sub / Neg / double on LweCiphertext): out = sum_{t<k} coef[t] * in[t] + addend over
+ * q < 2^62, k <= 4: the linear part of the gates (scheme/fhew/src/fhew.rs:27-29 `not`, 61-69 Table 1). */
+int fhe_lwe_lincomb(uint64_t q, int k, const int64_t *coef, const uint64_t *const *in, uint64_t addend, uint64_t *out, size_t count,
+                    fhe_mem mem, void *stream);
+/* scheme/fhew/src/rlwe.rs:193-202 `Rlwe::sample_extract(ct, index)`; `addend` (< q) is added to b. */
+int fhe_rlwe_sample_extract(uint64_t q, const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t addend,
+                            uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+/* scheme/fhew/src/bootstrapping.rs:149-155 `Bootstrapping::bootstrap(bk, f, ct)` for a batch of LWE ciphertexts under the
+ * ring key (ct_a [batch][N], ct_b [batch] over Q): mod_switch(q_ks) -> Lwe::key_switch -> mod_switch_odd(2N) ->
+ * blind_rotate -> sample_extract(0) (+ addend on b: Fhew::op's Q/8, scheme/fhew/src/fhew.rs:39).  One gate bootstrap. */
+int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b, int ks_d, const uint64_t *lwe_ksk_a,
+                       const uint64_t *lwe_ksk_b, const uint64_t *f, size_t f_stride, uint64_t addend, const uint64_t *ct_a,
+                       const uint64_t *ct_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+
 /* ---- RNS rings (CKKS) ------------------------------------------------------------------------------------ */
 typedef struct fhe_rns_ctx fhe_rns_ctx;   /* bases qs (L primes) and ps (K primes): util/src/ring/rns.rs:278-322 `Rns` */
 typedef struct fhe_ckks_key fhe_ckks_key; /* a key-switching key over qs ++ ps, evaluation domain, device resident */

@@ -93,6 +93,11 @@ def lib():
         L.fhe_ckks_key_destroy.argtypes = [vp]
         L.fhe_ckks_key_destroy.restype = None
         L.fhe_ckks_key_switch.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_lwe_mod_switch.argtypes = [C.c_uint64, C.c_uint64, vp, vp, sz, ci, ci, vp]
+        L.fhe_lwe_lincomb.argtypes = [C.c_uint64, ci, vp, vp, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_lwe_key_switch.argtypes = [C.c_uint64, ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
+        L.fhe_rlwe_sample_extract.argtypes = [C.c_uint64, vp, vp, sz, sz, C.c_uint64, vp, vp, sz, ci, vp]
+        L.fhe_fhew_bootstrap.argtypes = [vp, C.c_uint64, ci, ci, vp, vp, vp, sz, C.c_uint64, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_torus_ctx_create.argtypes = [ci, C.POINTER(vp)]
         L.fhe_torus_ctx_destroy.argtypes = [vp]
         L.fhe_torus_ctx_destroy.restype = None

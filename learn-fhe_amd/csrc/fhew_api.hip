@@ -267,6 +267,78 @@ int fhe_rlwe_automorphism(const fhe_ctx *ctx, const fhe_key *ak, size_t index, i
     return gadget_entry(ctx, ak, index, false, true, t, ct_a, ct_b, batch, mem, stream);
 }
 
+// util/src/zq.rs:128-140 via scheme/fhew/src/lwe.rs:90-99: v -> round(v * q_prime / q) (odd != 0: `mod_switch_odd`)
+int fhe_lwe_mod_switch(uint64_t q, uint64_t q_prime, const uint64_t *in, uint64_t *out, size_t count, int odd, fhe_mem mem, void *stream) {
+    if (q < 2 || q_prime < 2 || ((!in || !out) && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, count, mem, true, st), mo(out, count, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::lwe_mod_switch_kernel, dim3(grid_for(count)), dim3(256), 0, st, (const u64 *)mi.d, mo.d, count, (u64)q, (u64)q_prime, odd);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/fhew/src/lwe.rs:151-160 `Lwe::key_switch` over modulus q < 2^32
+int fhe_lwe_key_switch(uint64_t q, int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a,
+                       const uint64_t *ct_b, size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
+                       void *stream) {
+    fhe::DecompParams P;
+    int rc = make_decomp(q, log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    if (q >> 32) return FHE_ERR_UNSUPPORTED;
+    if (!ksk_a || !ksk_b || n_in == 0 || n_out == 0 || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = n_in * d;
+    Mirror mka(ksk_a, rows * n_out, mem, true, st), mkb(ksk_b, rows, mem, true, st), ma(ct_a, n_in * batch, mem, true, st),
+        mb(ct_b, batch, mem, true, st), moa(out_a, n_out * batch, mem, false, st), mob(out_b, batch, mem, false, st);
+    if (mka.rc | mkb.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::lwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
+                       (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    HIP_TRY(hipGetLastError());
+    rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
+// scheme/fhew/src/lwe.rs:22-75: out = sum_k coef[k] * in[k] + addend over q (the gates' linear parts, fhew.rs:27-29, 61-69)
+int fhe_lwe_lincomb(uint64_t q, int k, const int64_t *coef, const uint64_t *const *in, uint64_t addend, uint64_t *out, size_t count,
+                    fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || k < 1 || k > 4 || !coef || !in || addend >= q || (!out && count)) return FHE_ERR_INVALID;
+    for (int t = 0; t < k; ++t)
+        if (!in[t] && count) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror m0(in[0], count, mem, true, st), m1(k > 1 ? in[1] : nullptr, k > 1 ? count : 0, mem, true, st),
+        m2(k > 2 ? in[2] : nullptr, k > 2 ? count : 0, mem, true, st), m3(k > 3 ? in[3] : nullptr, k > 3 ? count : 0, mem, true, st),
+        mo(out, count, mem, false, st);
+    if (m0.rc | m1.rc | m2.rc | m3.rc | mo.rc) return FHE_ERR_HIP;
+    fhe::LinComb lc{};
+    lc.k = k;
+    const u64 *ptrs[4] = {m0.d, m1.d, m2.d, m3.d};
+    for (int t = 0; t < k; ++t) { lc.in[t] = ptrs[t]; lc.coef[t] = coef[t]; }
+    hipLaunchKernelGGL(fhe::lwe_lincomb_kernel, dim3(grid_for(count)), dim3(256), 0, st, lc, (u64)q, (u64)addend, mo.d, count);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/fhew/src/rlwe.rs:193-202 `Rlwe::sample_extract(ct, index)`, b += addend (mod q)
+int fhe_rlwe_sample_extract(uint64_t q, const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t addend,
+                            uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || addend >= q || !is_pow2(n) || index >= n || n > (1u << 30) || ((!ct_a || !ct_b || !out_a || !out_b) && batch))
+        return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st), moa(out_a, n * batch, mem, false, st),
+        mob(out_b, batch, mem, false, st);
+    if (ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rlwe_sample_extract_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
+                       (unsigned)n, batch, (unsigned)index, (u64)q, (u64)addend, moa.d, mob.d);
+    HIP_TRY(hipGetLastError());
+    int rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
 int fhe_bootstrap_key_create(const fhe_ctx *ctx, const fhe_key *brk, const fhe_key *ak, const int64_t *ak_t, int w,
                              fhe_bootstrap_key **out) {
     if (!out) return FHE_ERR_INVALID;
@@ -397,6 +469,46 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // workspace + h_err must be complete
     (void)hipFree(ws);
     if (rc == FHE_OK && h_err) rc = FHE_ERR_INVALID;  // an LWE coefficient outside the odd residues mod 2N (bootstrapping.rs:221)
+    return rc;
+}
+
+// scheme/fhew/src/bootstrapping.rs:149-155 `Bootstrapping::bootstrap(bk, f, ct)` for a batch, everything device side:
+// mod_switch(Q_ks) -> Lwe::key_switch (ksk over q_ks, decomposer (ks_log_b, ks_d)) -> mod_switch_odd(2N) -> blind_rotate ->
+// sample_extract(0); `addend` is added to the extracted b (Fhew::op adds Q/8, fhew.rs:39).
+// ct_a [batch][N], ct_b [batch] over Q (LWE under the ring key); lwe_ksk_a [ks_d * N][n_lwe], lwe_ksk_b [ks_d * N] over q_ks.
+int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b, int ks_d, const uint64_t *lwe_ksk_a,
+                       const uint64_t *lwe_ksk_b, const uint64_t *f, size_t f_stride, uint64_t addend, const uint64_t *ct_a,
+                       const uint64_t *ct_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    if (!bk || !lwe_ksk_a || !lwe_ksk_b || !f || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const fhe_ctx *ctx = bk->ctx;
+    const size_t n = size_t(1) << bk->brk->log_n, n_lwe = bk->brk->count;
+    const uint64_t big_q = ctx->q;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = n * ks_d;
+    Mirror mka(lwe_ksk_a, rows * n_lwe, mem, true, st), mkb(lwe_ksk_b, rows, mem, true, st), mf(f, f_stride ? n * batch : n, mem, true, st);
+    Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, batch, mem, true, st);
+    Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, batch, mem, false, st);
+    if (mka.rc | mkb.rc | mf.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    uint64_t *ws = nullptr;  // a1 [batch][n] | b1 [batch] | a2 [batch][n_lwe] | b2 [batch] | a3 | b3 | acc_a, acc_b [batch][n]
+    const size_t words = batch * (n + 1 + 2 * (n_lwe + 1) + 2 * n);
+    HIP_TRY(hipMalloc((void **)&ws, words * sizeof(u64)));
+    auto U = [](u64 *p) { return (uint64_t *)p; };
+    uint64_t *a1 = ws, *b1 = a1 + batch * n, *a2 = b1 + batch, *b2 = a2 + batch * n_lwe, *a3 = b2 + batch, *b3 = a3 + batch * n_lwe,
+        *ra = b3 + batch, *rb = ra + batch * n;
+    int rc = fhe_lwe_mod_switch(big_q, q_ks, U(ma.d), a1, batch * n, 0, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_lwe_mod_switch(big_q, q_ks, U(mb.d), b1, batch, 0, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_lwe_key_switch(q_ks, ks_log_b, ks_d, U(mka.d), U(mkb.d), a1, b1, n, n_lwe, a2, b2, batch, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_lwe_mod_switch(q_ks, 2 * n, a2, a3, batch * n_lwe, 1, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_lwe_mod_switch(q_ks, 2 * n, b2, b3, batch, 1, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_blind_rotate(bk, a3, b3, U(mf.d), f_stride, ra, rb, batch, FHE_MEM_DEVICE, stream, nullptr, nullptr);
+    if (rc == FHE_OK) rc = fhe_rlwe_sample_extract(big_q, ra, rb, n, 0, addend, U(moa.d), U(mob.d), batch, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = moa.sync_out(st);
+    if (rc == FHE_OK) rc = mob.sync_out(st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
+    (void)hipFree(ws);
     return rc;
 }
 

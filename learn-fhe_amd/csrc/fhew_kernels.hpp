@@ -72,6 +72,92 @@ static __global__ void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__re
     }
 }
 
+// ---- LWE side of the FHEW gate: scheme/fhew/src/lwe.rs:90-99, 151-160 ----------
+// util/src/zq.rs:128-130 `mod_switch` and 132-140 `mod_switch_odd`: f64 arithmetic, f64::round = half away from zero,
+// `as i64` / `as u64` saturating casts, rem_euclid.  IEEE double multiply and divide, no contraction.
+__device__ __forceinline__ u64 zq_mod_switch(u64 v, u64 q, u64 q_prime, bool odd) {
+    const double x = __ddiv_rn(__dmul_rn((double)v, (double)q_prime), (double)q);
+    if (!odd) {
+        const double r = round(x);
+        const long long i = r >= 9.2233720368547758e18 ? 0x7fffffffffffffffll : (long long)r;  // x >= 0 here
+        return (u64)i % q_prime;
+    }
+    const double u = floor(x);
+    if (u == 0.0) return (u64)round(x) % q_prime;
+    return ((u64)u | 1ull) % q_prime;
+}
+
+static __global__ void lwe_mod_switch_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 q, u64 q_prime, int odd) {
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
+        out[idx] = zq_mod_switch(in[idx], q, q_prime, odd != 0);
+}
+
+// scheme/fhew/src/lwe.rs:151-160 `Lwe::key_switch`: one thread per (ciphertext, output coefficient); column n_out carries b.
+// ksk_a [d * n_in][n_out], ksk_b [d * n_in]; row j * n_in + i = digit j of input coefficient i (`decompose(a).flatten()`).
+// q < 2^32 (the FHEW key-switching moduli are 2^16 .. 2^20), so products fit 64 bits.
+static __global__ void lwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
+                                             size_t batch, const u64 *__restrict__ ksk_a, const u64 *__restrict__ ksk_b, DecompParams P,
+                                             u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    const size_t total = size_t(n_out + 1) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / (n_out + 1);
+        const unsigned col = unsigned(idx - p * (n_out + 1));
+        u64 acc = 0;
+        for (unsigned i = 0; i < n_in; ++i) {
+            u64 c = decomp_init(ct_a[p * n_in + i], P);
+            for (int j = 0; j < P.d; ++j) {
+                const u64 dg = decomp_next(c, P);
+                const size_t row = size_t(j) * n_in + i;
+                const u64 kv = col < n_out ? ksk_a[row * n_out + col] : ksk_b[row];
+                acc = (acc + kv * dg % P.q) % P.q;
+            }
+        }
+        if (col < n_out) out_a[p * n_out + col] = acc;
+        else out_b[p] = (acc + ct_b[p]) % P.q;
+    }
+}
+
+// scheme/fhew/src/lwe.rs:22-75 (Add/Sub/Neg/double on LweCiphertext): out = sum_k coef[k] * in[k] + addend (mod q), q < 2^62.
+// |coef| is 1 or 2 for the gates of scheme/fhew/src/fhew.rs:61-69, so the scalar product is a short double-and-add.
+struct LinComb {
+    const u64 *in[4];
+    long long coef[4];
+    int k;
+};
+static __global__ void lwe_lincomb_kernel(LinComb lc, u64 q, u64 addend, u64 *__restrict__ out, size_t count) {
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x) {
+        u64 acc = addend;
+        for (int t = 0; t < lc.k; ++t) {
+            const long long c = lc.coef[t];
+            u64 m = c < 0 ? 0ull - (u64)c : (u64)c;
+            u64 x = lc.in[t][idx], term = 0;
+            while (m) {
+                if (m & 1) term = csub(term + x, q);
+                x = csub(x + x, q);
+                m >>= 1;
+            }
+            if (c < 0 && term) term = q - term;
+            acc = csub(acc + term, q);
+        }
+        out[idx] = acc;
+    }
+}
+
+// scheme/fhew/src/rlwe.rs:193-202 `Rlwe::sample_extract(ct, i)`; `addend` is added to b (Fhew::op's + Q/8, fhew.rs:39)
+static __global__ void rlwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
+                                                  u64 q, u64 addend, u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    const size_t total = size_t(n) * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned j = unsigned(idx - p * n);
+        u64 v;
+        if (j <= i) v = ct_a[p * n + (i - j)];
+        else { v = ct_a[p * n + (n + i - j)]; v = v ? q - v : 0; }
+        out_a[idx] = v;
+        if (j == 0) out_b[p] = csub(ct_b[p * n + i] + addend, q);
+    }
+}
+
 // ---- wave-owned ring element -------------------------------------------------------------------
 template <int LOG_N>
 struct WaveRing {

@@ -159,6 +159,53 @@ class GadgetKey:
                 "fhe_rlwe_automorphism")
 
 
+def lwe_mod_switch(q, q_prime, v, odd=False):
+    """util/src/zq.rs:128-140 (scheme/fhew/src/lwe.rs:90-99)."""
+    p, cnt, mem, st = _buf(v)
+    out = _like(v, tuple(v.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_lwe_mod_switch(q, q_prime, p, po, cnt, int(odd), mem, st), "fhe_lwe_mod_switch")
+    return out
+
+
+def lwe_key_switch(q, log_b, d, ksk_a, ksk_b, ct_a, ct_b, n_in, n_out):
+    """scheme/fhew/src/lwe.rs:151-160."""
+    pka, _, mem, st = _buf(ksk_a)
+    pkb, _, _, _ = _buf(ksk_b)
+    pa, cnt, _, _ = _buf(ct_a)
+    pb, _, _, _ = _buf(ct_b)
+    batch = cnt // n_in
+    out_a, out_b = _like(ct_a, (batch, n_out)), _like(ct_a, (batch,))
+    poa, _, _, _ = _buf(out_a)
+    pob, _, _, _ = _buf(out_b)
+    L.check(L.lib().fhe_lwe_key_switch(q, log_b, d, pka, pkb, pa, pb, n_in, n_out, poa, pob, batch, mem, st), "fhe_lwe_key_switch")
+    return out_a, out_b
+
+
+def lwe_lincomb(q, coefs, xs, addend=0):
+    """scheme/fhew/src/lwe.rs:22-75: sum_k coefs[k] * xs[k] + addend over q (element-wise)."""
+    k = len(xs)
+    bufs = [_buf(x) for x in xs]
+    ptrs = (C.c_void_p * k)(*[b[0] for b in bufs])
+    cf = (C.c_int64 * k)(*coefs)
+    out = _like(xs[0], tuple(xs[0].shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_lwe_lincomb(q, k, cf, ptrs, addend, po, bufs[0][1], bufs[0][2], bufs[0][3]), "fhe_lwe_lincomb")
+    return out
+
+
+def rlwe_sample_extract(q, ct_a, ct_b, n, index, addend=0):
+    """scheme/fhew/src/rlwe.rs:193-202."""
+    pa, cnt, mem, st = _buf(ct_a)
+    pb, _, _, _ = _buf(ct_b)
+    batch = cnt // n
+    out_a, out_b = _like(ct_a, (batch, n)), _like(ct_a, (batch,))
+    poa, _, _, _ = _buf(out_a)
+    pob, _, _, _ = _buf(out_b)
+    L.check(L.lib().fhe_rlwe_sample_extract(q, pa, pb, n, index, addend, poa, pob, batch, mem, st), "fhe_rlwe_sample_extract")
+    return out_a, out_b
+
+
 class BootstrapKey:
     """scheme/fhew/src/bootstrapping.rs:93-113 (brk + ak part)."""
 
@@ -172,6 +219,22 @@ class BootstrapKey:
         h, self._h = getattr(self, "_h", None), None
         if h:
             L.lib().fhe_bootstrap_key_destroy(h)
+
+    def bootstrap(self, q_ks, ks_log_b, ks_d, lwe_ksk_a, lwe_ksk_b, f, ct_a, ct_b, addend=0):
+        """scheme/fhew/src/bootstrapping.rs:149-155 for a batch: ct_a [batch][N], ct_b [batch] over Q -> LWE (a [batch][N], b)."""
+        n = self.brk.n
+        pka, _, mem, st = _buf(lwe_ksk_a)
+        pkb, _, _, _ = _buf(lwe_ksk_b)
+        pf, fcnt, _, _ = _buf(f)
+        pa, cnt, _, _ = _buf(ct_a)
+        pb, batch, _, _ = _buf(ct_b)
+        assert cnt == batch * n
+        out_a, out_b = _like(ct_a, (batch, n)), _like(ct_a, (batch,))
+        poa, _, _, _ = _buf(out_a)
+        pob, _, _, _ = _buf(out_b)
+        L.check(L.lib().fhe_fhew_bootstrap(self._h, q_ks, ks_log_b, ks_d, pka, pkb, pf, 0 if fcnt == n else n, addend, pa, pb, poa, pob,
+                                           batch, mem, st), "fhe_fhew_bootstrap")
+        return out_a, out_b
 
     def blind_rotate(self, lwe_a, lwe_b, f, want_schedule=False):
         """scheme/fhew/src/bootstrapping.rs:158-209 for a batch: lwe_a [batch][n_lwe], lwe_b [batch], f [n] or [batch][n]."""
@@ -360,3 +423,56 @@ def tlwe_key_switch(log_b, d, ksk_a, ksk_b, ct_a, ct_b, n_in, n_out):
     pob, _, _, _ = _buf(out_b)
     L.check(L.lib().fhe_tlwe_key_switch(log_b, d, pka, pkb, pa, pb, n_in, n_out, poa, pob, batch, mem, st), "fhe_tlwe_key_switch")
     return out_a, out_b
+
+
+class Fhew:
+    """Host mirror of `Fhew` (scheme/fhew/src/fhew.rs:16-70) over batches of LWE ciphertexts (a [batch][N], b [batch]) under the
+    ring key: each gate is a linear combination, one `BootstrapKey.bootstrap` with the gate's table, and + Q/8."""
+
+    TABLES = {"and": (0, 0, 0, 1), "nand": (1, 1, 1, 0), "or": (0, 1, 1, 1), "nor": (1, 0, 0, 0), "xor": (0, 1, 1, 1),
+              "xnor": (1, 0, 0, 0), "majority": (0, 0, 0, 1)}
+
+    def __init__(self, bk, q_ks, ks_log_b, ks_d, lwe_ksk_a, lwe_ksk_b):
+        self.bk, self.q_ks, self.ks_log_b, self.ks_d, self.ksk_a, self.ksk_b = bk, q_ks, ks_log_b, ks_d, lwe_ksk_a, lwe_ksk_b
+        self.big_q, self.n = bk.ctx.q, bk.brk.n
+        self.big_q_by_8 = self._round_div(self.big_q, 8)
+        self.big_q_by_4 = self._round_div(self.big_q, 4)
+        self._f = {}
+
+    @staticmethod
+    def _round_div(q, k):
+        # BootstrappingParam::big_q_by_8 (scheme/fhew/src/bootstrapping.rs:73-79): Zq::from_f64(q, q as f64 / k as f64)
+        import math
+        x = float(q) / float(k)
+        fl = math.floor(x)
+        return (int(fl) + (1 if x - fl >= 0.5 else 0)) % q  # f64::round: half away from zero (x > 0)
+
+    def table_poly(self, table, like):
+        """fhew.rs:32-37: f = table.flat_map(|out| repeat(+-Q/8).take(q_by_8)), q = 2N"""
+        key = (tuple(table), _is_torch(like))
+        if key not in self._f:
+            vals = [(self.big_q - self.big_q_by_8) % self.big_q, self.big_q_by_8]
+            f = np.array([vals[o] for o in table for _ in range(2 * self.n // 8)], dtype=np.uint64)
+            if _is_torch(like):
+                import torch
+                f = torch.from_numpy(f.view(np.int64)).to(like.device)
+            self._f[key] = f
+        return self._f[key]
+
+    def not_(self, ct):
+        a, b = ct
+        return lwe_lincomb(self.big_q, [-1], [a]), lwe_lincomb(self.big_q, [-1], [b], self.big_q_by_4)
+
+    def _op(self, name, coefs, cts):
+        a = lwe_lincomb(self.big_q, coefs, [c[0] for c in cts])
+        b = lwe_lincomb(self.big_q, coefs, [c[1] for c in cts])
+        return self.bk.bootstrap(self.q_ks, self.ks_log_b, self.ks_d, self.ksk_a, self.ksk_b, self.table_poly(self.TABLES[name], a), a, b,
+                                 addend=self.big_q_by_8)
+
+    def and_(self, c0, c1): return self._op("and", [1, 1], [c0, c1])          # noqa: E704
+    def nand(self, c0, c1): return self._op("nand", [1, 1], [c0, c1])         # noqa: E704
+    def or_(self, c0, c1): return self._op("or", [1, 1], [c0, c1])            # noqa: E704
+    def nor(self, c0, c1): return self._op("nor", [1, 1], [c0, c1])           # noqa: E704
+    def xor(self, c0, c1): return self._op("xor", [2, -2], [c0, c1])          # noqa: E704
+    def xnor(self, c0, c1): return self._op("xnor", [2, -2], [c0, c1])        # noqa: E704
+    def majority(self, c0, c1, c2): return self._op("majority", [1, 1, 1], [c0, c1, c2])  # noqa: E704

@@ -262,3 +262,140 @@ def test_blind_rotate_decrypt_level(fhe, torch_cuda):
         pt = P.rlwe_decrypt(q, z, L(host(oa)[i]), L(host(ob)[i]))
         exp = f[mu] if mu < n else P.zq_neg(q, f[mu - n])
         assert abs(P.zq_to_i64(q, (pt[0] - exp) % q)) < (1 << 30)
+
+
+# ---- the LWE side of the gate and the whole gate bootstrap ---------------------------------
+
+
+def test_lwe_mod_switch(fhe, cref, torch_cuda):
+    """util/src/zq.rs:128-140 through scheme/fhew/src/lwe.rs:90-99: the f64 rule, bit for bit"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    for q, qp, odd in [(268369921, 1 << 16, False), (1 << 16, 1024, True), (18014398509404161, 1 << 16, False), (1 << 16, 2048, True),
+                       (1152921504606748673, 1 << 20, False), (1 << 20, 4096, True), (1073707009, 12289, False)]:
+        v = rng.integers(0, q, size=3000, dtype=np.uint64)
+        v[:8] = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1, q // 3]
+        if odd:
+            v[8:40] = np.arange(32, dtype=np.uint64)          # floor(x) == 0 branch and its neighbours
+        out = host(fhe.lwe_mod_switch(q, qp, dev(torch_cuda, v), odd=odd))
+        ref = cref.mod_switch_odd if odd else cref.mod_switch
+        assert L(out) == [ref(q, int(x), qp) for x in v], (q, qp, odd)
+    v = rng.integers(0, 1 << 16, size=37, dtype=np.uint64)
+    assert L(fhe.lwe_mod_switch(1 << 16, 1024, v, odd=True)) == [cref.mod_switch_odd(1 << 16, int(x), 1024) for x in v]  # host memory
+    assert fhe.lwe_mod_switch(1 << 16, 1024, np.zeros(0, dtype=np.uint64)).size == 0
+
+
+def test_lwe_key_switch_and_sample_extract(fhe, cref, torch_cuda):
+    """scheme/fhew/src/lwe.rs:151-160 and rlwe.rs:193-202"""
+    for q, lb, d, n_in, n_out, batch in [(1 << 16, 4, 4, 128, 20, 5), (1 << 20, 5, 4, 64, 33, 3), (12289, 3, 4, 32, 7, 2)]:
+        ksk_a, ksk_b = rand_u64(1, q, (d * n_in, n_out)), rand_u64(2, q, d * n_in)
+        ct_a, ct_b = rand_u64(3, q, (batch, n_in)), rand_u64(4, q, batch)
+        ct_a[0, :4] = [0, q - 1, q // 2, 1]
+        oa, ob = fhe.lwe_key_switch(q, lb, d, dev(torch_cuda, ksk_a), dev(torch_cuda, ksk_b), dev(torch_cuda, ct_a), dev(torch_cuda, ct_b),
+                                    n_in, n_out)
+        for i in range(batch):
+            ea, eb = cref.lwe_key_switch(q, lb, d, ksk_a, ksk_b, ct_a[i], int(ct_b[i]))
+            assert np.array_equal(host(oa)[i], ea) and int(host(ob)[i]) == eb, (q, i)
+    with pytest.raises(fhe.FheError):
+        fhe.lwe_key_switch(1 << 40, 4, 4, ksk_a, ksk_b, ct_a, ct_b, n_in, n_out)  # q >= 2^32 is outside this entry's range
+    q, n, batch = 18014398509404161, 256, 4
+    a, b = rand_u64(5, q, (batch, n)), rand_u64(6, q, (batch, n))
+    a[0, :3] = 0
+    for idx in (0, 1, 100, n - 1):
+        oa, ob = fhe.rlwe_sample_extract(q, dev(torch_cuda, a), dev(torch_cuda, b), n, idx)
+        for i in range(batch):
+            ea, eb = cref.sample_extract(q, a[i], b[i], idx)
+            assert np.array_equal(host(oa)[i], ea) and int(host(ob)[i]) == eb
+    oa, ob = fhe.rlwe_sample_extract(q, a, b, n, 0, addend=q - 1)
+    assert L(ob) == [(int(x) + q - 1) % q for x in b[:, 0]]
+
+
+def test_lwe_lincomb(fhe, torch_cuda):
+    q = 18014398509404161
+    xs = [rand_u64(10 + i, q, (3, 50)) for i in range(3)]
+    xs[0][0, :2] = [0, q - 1]
+    for coefs, addend in [([1, 1], 0), ([2, -2], 0), ([-1], q // 4), ([1, 1, 1], 5), ([7, -3, 2], q - 1)]:
+        out = fhe.lwe_lincomb(q, coefs, [dev(torch_cuda, x) for x in xs[:len(coefs)]], addend)
+        exp = [(sum(c * int(x.ravel()[i]) for c, x in zip(coefs, xs)) + addend) % q for i in range(150)]
+        assert L(host(out)) == exp, coefs
+
+
+def test_fhew_bootstrap_vs_oracle(fhe, cref, torch_cuda):
+    """scheme/fhew/src/bootstrapping.rs:149-155, the whole chain on uniform-random keys, bit-exact against the oracle's steps"""
+    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 128, 6, 3, 3, 6, 4
+    q_ks, kb, kd = 1 << 16, 4, 4
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, 5, 4, w, n_lwe, seed=70)
+    ksk_a, ksk_b = rand_u64(71, q_ks, (kd * n, n_lwe)), rand_u64(72, q_ks, kd * n)
+    ct_a, ct_b = rand_u64(73, q, (batch, n)), rand_u64(74, q, batch)
+    f = rand_u64(75, q, n)
+    addend = q // 8
+    oa, ob = bk.bootstrap(q_ks, kb, kd, dev(torch_cuda, ksk_a), dev(torch_cuda, ksk_b), dev(torch_cuda, f), dev(torch_cuda, ct_a),
+                          dev(torch_cuda, ct_b), addend=addend)
+    for i in range(batch):
+        a1 = np.array([cref.mod_switch(q, int(x), q_ks) for x in ct_a[i]], dtype=np.uint64)
+        b1 = cref.mod_switch(q, int(ct_b[i]), q_ks)
+        a2, b2 = cref.lwe_key_switch(q_ks, kb, kd, ksk_a, ksk_b, a1, b1)
+        a3 = np.array([cref.mod_switch_odd(q_ks, int(x), 2 * n) for x in a2], dtype=np.uint64)
+        b3 = cref.mod_switch_odd(q_ks, int(b2), 2 * n)
+        ra, rb = cref.blind_rotate(q, n, w, lb, d, 5, 4, brk, ak, ts, f, a3, b3)
+        ea, eb = cref.sample_extract(q, ra, rb, 0)
+        assert np.array_equal(host(oa)[i], ea) and int(host(ob)[i]) == (eb + addend) % q, i
+    # host-memory entry
+    ha, hb = bk.bootstrap(q_ks, kb, kd, ksk_a, ksk_b, f, ct_a[:1], ct_b[:1], addend=addend)
+    assert np.array_equal(ha, host(oa)[:1]) and np.array_equal(hb, host(ob)[:1])
+
+
+def test_fhew_gates_decrypt(fhe, torch_cuda):
+    """The reference's own gate test (scheme/fhew/src/fhew/boolean.rs:256-290) with its `single_key_testing_param`
+    (boolean.rs:225-239): every gate on every input combination decrypts to the truth table."""
+    from oracle import pyref as P
+    rnd = random.Random(2024)
+    log_q, log_n, log_b, d, w = 28, 9, 7, 4, 10
+    n_lwe, q_ks, kb, kd = 100, 1 << 16, 4, 4
+    n = 1 << log_n
+    q = next(P.two_adic_primes(log_q, log_n + 1))
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    dec, dec_ks = P.Base2Decomposor(q, log_b, d), P.Base2Decomposor(q_ks, kb, kd)
+    z = [rnd.randint(-1, 1) for _ in range(n)]
+    s = [rnd.randint(-1, 1) for _ in range(n_lwe)]
+    one = [1] + [0] * (n - 1)
+    brk = [P.rgsw_encrypt(q, dec, z, P.monomial_mul(q, one, sj), rnd) for sj in s]
+    ts = P.ak_t(n, w)
+    ak = [P.rlwe_ak_gen(q, dec, t, z, rnd) for t in ts]
+    ksk_a, ksk_b = P.lwe_ksk_gen(q_ks, dec_ks, s, z, rnd)
+    ctx = fhe.NttContext(q)
+    gk = fhe.GadgetKey(ctx, log_b, d, U([k[0] for k in brk]), U([k[1] for k in brk]), n, rgsw=True)
+    ga = fhe.GadgetKey(ctx, log_b, d, U([k[0] for k in ak]), U([k[1] for k in ak]), n, rgsw=False)
+    bk = fhe.BootstrapKey(ctx, gk, ga, ts, w)
+    ev = fhe.Fhew(bk, q_ks, kb, kd, dev(torch_cuda, U(ksk_a)), dev(torch_cuda, U(ksk_b)))
+    delta = q / 4.0
+
+    def encrypt(bits):
+        cts = [P.lwe_sk_encrypt(q, z, P.zq_from_f64(q, float(m) * delta), rnd) for m in bits]
+        return dev(torch_cuda, U([c[0] for c in cts])), dev(torch_cuda, U([c[1] for c in cts]))
+
+    def decrypt(ct):
+        a, b = host(ct[0]), host(ct[1])
+        out = []
+        for i in range(a.shape[0]):
+            pt = P.lwe_decrypt(q, z, L(a[i]), int(b[i]))
+            m = P.zq_from_f64(4, float(pt) / delta)
+            assert m in (0, 1), m
+            out.append(m)
+        return out
+
+    m0 = [(m >> 0) & 1 for m in range(4)]
+    m1 = [(m >> 1) & 1 for m in range(4)]
+    c0, c1 = encrypt(m0), encrypt(m1)
+    assert decrypt(c0) == m0 and decrypt(ev.not_(c0)) == [1 - x for x in m0]
+    assert decrypt(ev.and_(c0, c1)) == [x & y for x, y in zip(m0, m1)]
+    assert decrypt(ev.nand(c0, c1)) == [1 - (x & y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.or_(c0, c1)) == [x | y for x, y in zip(m0, m1)]
+    assert decrypt(ev.nor(c0, c1)) == [1 - (x | y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.xor(c0, c1)) == [x ^ y for x, y in zip(m0, m1)]
+    assert decrypt(ev.xnor(c0, c1)) == [1 - (x ^ y) for x, y in zip(m0, m1)]
+    t0 = [(m >> 0) & 1 for m in range(8)]
+    t1 = [(m >> 1) & 1 for m in range(8)]
+    t2 = [(m >> 2) & 1 for m in range(8)]
+    assert decrypt(ev.majority(encrypt(t0), encrypt(t1), encrypt(t2))) == [(x & y) | (y & u) | (u & x) for x, y, u in zip(t0, t1, t2)]
+    # a two-level circuit: outputs of one gate are valid inputs of the next (noise refreshed)
+    assert decrypt(ev.xor(ev.nand(c0, c1), ev.or_(c0, c1))) == [(1 - (x & y)) ^ (x | y) for x, y in zip(m0, m1)]
