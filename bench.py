@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 ALGO_BYTES_PER_NTT = 16 * (1 << LOG_N)  # 8N read + 8N write
 
 
-def cpu_baseline(sample_per_thread=48):
+def cpu_baseline(sample_per_thread=512, reps=4):
     """Oracle C restatement (kind = "port": same u128 % q arithmetic and loop nest as the Rust reference,
     which cannot be built here) on the host cores of this box: forward+inverse over a bounded sample."""
     import numpy as np
@@ -46,50 +46,127 @@ def cpu_baseline(sample_per_thread=48):
     polys = sample_per_thread * threads
     a = rng.integers(0, Q, size=n * polys, dtype=np.uint64)
     t0 = time.perf_counter()
-    cref.ntt_fwd_inplace(Q, a, n, threads)
-    cref.ntt_inv_inplace(Q, a, n, threads)
-    tm = time.perf_counter() - t0
+    for _ in range(reps):
+        cref.ntt_fwd_inplace(Q, a, n, threads)
+        cref.ntt_inv_inplace(Q, a, n, threads)
+    tm = (time.perf_counter() - t0) / reps
     return {"value": 2 * polys / tm, "unit": "NTTs/sec", "cores": threads, "kind": "port",
-            "sample": "%d polynomials (fwd+inv) of the bench workload, OpenMP over the batch; "
-                      "single-thread: %.1f NTTs/sec on 16 polynomials" % (polys, single),
+            "sample": "%d polynomials (fwd+inv) x %d repetitions of the bench workload, OpenMP over the batch; "
+                      "single-thread: %.1f NTTs/sec on 16 polynomials" % (polys, reps, single),
             "single_thread_value": single}
+
+
+def _timeit(torch, fn, reps):
+    fn()  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
 
 
 def fhew_bench(torch, F, dev, local_rank, batches=(64, 1024), reps=3):
     """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
     rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
-    N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident."""
-    from oracle import pyref as P  # only ak_t(): the exponent list [-5, 5, 25, ...] mod 2N
+    N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident; and the
+    whole gate bootstrap around it (bootstrapping.rs:149-155: mod switch, LWE key switch over 2^16 with base 2^4 d = 4
+    as in the reference's parameter sets, odd mod switch, blind rotation, sample extract)."""
     q, n, log_b, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 100
+    q_ks, kb, kd = 1 << 16, 4, 4
     ctx = F.NttContext(q, device=local_rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
-    rnd = lambda *shape: torch.randint(0, q, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
+    rnd = lambda *shape, m=q: torch.randint(0, m, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
     brk = F.GadgetKey(ctx, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n, rgsw=True)
     ak = F.GadgetKey(ctx, log_b, d, rnd(w + 1, d, n), rnd(w + 1, d, n), n, rgsw=False)
-    bk = F.BootstrapKey(ctx, brk, ak, P.ak_t(n, w), w)
+    bk = F.BootstrapKey(ctx, brk, ak, F.ak_t(n, w), w)
+    ksk_a, ksk_b = rnd(kd * n, n_lwe, m=q_ks), rnd(kd * n, m=q_ks)
     f = rnd(n)
-    out = {"workload": "cfg3: LMKCDEY blind rotation N=2^10 q=%d log_b=6 d=9 n_lwe=100 w=10" % q}
+    out = {"workload": "cfg3: LMKCDEY blind rotation N=2^10 q=%d log_b=6 d=9 n_lwe=100 w=10; gate = + LWE key switch "
+                       "q_ks=2^16 (4,4), mod switches, sample extract" % q}
     for batch in batches:
         lwe_a = torch.randint(0, n, (batch, n_lwe), dtype=torch.int64, device=dev, generator=gen) * 2 + 1
         lwe_b = torch.randint(0, 2 * n, (batch,), dtype=torch.int64, device=dev, generator=gen)
-        bk.blind_rotate(lwe_a, lwe_b, f)  # warm-up
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            bk.blind_rotate(lwe_a, lwe_b, f)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = _timeit(torch, lambda: bk.blind_rotate(lwe_a, lwe_b, f), reps)
         out["blind_rotations_per_sec_batch%d" % batch] = batch / dt
+    batch = batches[-1]
+    ct_a, ct_b = rnd(batch, n), rnd(batch)
+    dt = _timeit(torch, lambda: bk.bootstrap(q_ks, kb, kd, ksk_a, ksk_b, f, ct_a, ct_b, addend=q // 8), reps)
+    out["gate_bootstraps_per_sec_batch%d" % batch] = batch / dt
     ca, cb = rnd(4096, n), rnd(4096, n)
-    brk.external_product_(0, ca, cb)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(10):
-        brk.external_product_(i % n_lwe, ca, cb)
-    torch.cuda.synchronize()
-    out["external_products_per_sec_batch4096"] = 10 * 4096 / (time.perf_counter() - t0)
+    dt = _timeit(torch, lambda: brk.external_product_(0, ca, cb), 10)
+    out["external_products_per_sec_batch4096"] = 4096 / dt
     return out
+
+
+def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
+    """BASELINE config 4 on one GPU: CKKS key switch (scheme/ckks/src/ckks.rs:284-293) with CkksParam::new(15, 60, 8):
+    N = 2^15, 8 + 8 sixty-bit primes (two_adic_primes(60, 16)), `batch` ciphertexts resident in HBM."""
+    import ctypes as C
+    n, big_l = 1 << 15, 8
+    primes = (C.c_uint64 * (2 * big_l))()
+    assert F.lib().fhe_two_adic_primes(60, 16, 2 * big_l, primes) == 2 * big_l
+    qs, ps = list(primes)[:big_l], list(primes)[big_l:]
+    rns = F.RnsContext(qs, ps, device=local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    limbs = lambda ms, *lead: torch.stack([torch.randint(0, m, (*lead, n), dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
+                                           for m in ms], dim=len(lead)).contiguous()
+    key = F.CkksKey(rns, limbs(qs + ps), limbs(qs + ps), n)
+    cb, ca = limbs(qs, batch), limbs(qs, batch)
+    dt = _timeit(torch, lambda: key.key_switch_(cb, ca), reps)
+    return {"workload": "cfg4: CKKS key switch N=2^15, 8+8 60-bit primes, batch=%d" % batch, "key_switches_per_sec": batch / dt,
+            "ms_per_key_switch": dt / batch * 1e3}
+
+
+def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
+    """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
+    bootstrapping.rs:139-165) at N = 2^10, k = 1: mod switch, n_lwe = 630 CMUXes (base 2^7, d = 3 -- the reference ships
+    no N = 2^10 parameter set; these are the usual ones for that ring), sample extract, TLWE key switch (base 2^4, d = 5
+    as in the reference's test).  Exact torus arithmetic (two-prime CRT), uniform-random keys."""
+    n, n_lwe, log_b, d, ks_lb, ks_d = 1024, 630, 7, 3, 4, 5
+    t = F.TorusContext(device=local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    rnd = lambda *shape: torch.randint(-(1 << 63), (1 << 63) - 1, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
+    key = F.TggswKey(t, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n)
+    ksa, ksb = rnd(n * ks_d, n_lwe), rnd(n * ks_d)
+    v = rnd(n)
+    a_raw, b_raw = rnd(batch, n_lwe), rnd(batch)
+
+    def gate():
+        at, bt = F.TorusContext.mod_switch(a_raw, n), F.TorusContext.mod_switch(b_raw, n)
+        oa, ob = key.blind_rotate(at, bt, v)
+        ea, eb = F.tglwe_sample_extract(oa, ob, n, 0)
+        return F.tlwe_key_switch(ks_lb, ks_d, ksa, ksb, ea, eb, n, n_lwe)
+
+    dt = _timeit(torch, gate, reps)
+    return {"workload": "cfg5 (one GPU's share): TFHE gate bootstrap N=2^10 k=1 n_lwe=630 (7,3) ks (4,5), batch=%d" % batch,
+            "gate_bootstraps_per_sec": batch / dt}
+
+
+def cpu_fhew_baseline():
+    """cfg3 blind rotation of ONE ciphertext on one host core with the oracle's C restatement (the reference is single-threaded)."""
+    import numpy as np
+    from oracle import cref
+    q, n, log_b, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 100
+    rng = np.random.Generator(np.random.PCG64(6))
+    brk = rng.integers(0, q, size=(n_lwe, 2, 2 * d, n), dtype=np.uint64)
+    ak = rng.integers(0, q, size=(w + 1, 2, d, n), dtype=np.uint64)
+    f = rng.integers(0, q, size=n, dtype=np.uint64)
+    lwe_a = rng.integers(0, n, size=n_lwe, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    ts = []
+    x, q2 = 1, 2 * n
+    for _ in range(w):
+        x = x * 5 % q2
+        ts.append(x if x < q2 // 2 else x - q2)
+    ts = [-5] + ts
+    cref.ntt_fwd(q, f, n)  # twiddle set-up outside the timed region
+    t0 = time.perf_counter()
+    cref.blind_rotate(q, n, w, log_b, d, log_b, d, brk, ak, ts, f, lwe_a, 7)
+    dt = time.perf_counter() - t0
+    return {"blind_rotations_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg3 blind rotation"}
 
 
 def load_traffic():
@@ -110,7 +187,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="polynomials per GPU (default: BASELINE cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the final all_gather of results (not in value)")
-    ap.add_argument("--no-fhew", action="store_true", help="skip the secondary FHEW blind-rotation figures")
+    ap.add_argument("--no-fhew", action="store_true", help="skip the secondary figures (cfg3 FHEW, cfg4 CKKS, cfg5 TFHE)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the control path)")
     ap.add_argument("--single-device", action="store_true",
@@ -198,7 +275,7 @@ def main():
             "config": {"workload": "cfg2: batched forward+inverse negacyclic NTT, N=2^14, q=%d, batch=%d per GPU, "
                                    "HBM-resident" % (Q, args.batch), "n": n, "q": Q, "batch_per_gpu": args.batch,
                        "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<ArithPM<60>,14,4,1> (forward transform)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "ntt14_fwd_kernel<ArithPM<60>> (forward transform)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic() if args.batch == BATCH else None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
@@ -208,8 +285,12 @@ def main():
             out["final_gather_ms"] = gather_ms
         if n_gpus == 1 and not args.no_fhew:
             out["fhew"] = fhew_bench(torch, F, dev, local_rank)
+            out["ckks"] = ckks_bench(torch, F, dev, local_rank)
+            out["tfhe"] = tfhe_bench(torch, F, dev, local_rank)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if not args.no_fhew:
+                out["cpu_baseline"]["fhew"] = cpu_fhew_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

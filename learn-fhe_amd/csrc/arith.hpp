@@ -14,6 +14,15 @@
 
 namespace fhe {
 
+// Pointers that kernels read out of a descriptor in memory carry no address space: loads through them compile to FLAT
+// instructions, which count against BOTH vmcnt and lgkmcnt and so serialise against every LDS wait.  Twiddle tables live in
+// HBM: say so.
+#define FHE_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const FHE_GLOBAL T *as_global(const T *p) {
+    return (const FHE_GLOBAL T *)p;
+}
+
 template <int I, int END, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < END) {
@@ -28,7 +37,7 @@ struct ModDesc {
     const TwPair *tw, *twi;
     u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
     u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
-    // pseudo-Mersenne fast path: q = 2^pm_b - pm_c, twiddles in PmTw form; pm_b = 0: not eligible
+    // pseudo-Mersenne fast path: q = 2^pm_b - pm_c, twiddles in the packed 8-byte PmRaw form; pm_b = 0: not eligible
     const u64 *tww, *twwi;
     unsigned pm_c;
     int pm_b;
@@ -37,24 +46,29 @@ struct ModDesc {
 struct ArithShoup {
     struct K {
         u64 q, q2;
-        const TwPair *tw, *twi;
+        const FHE_GLOBAL TwPair *tw, *twi;
         u64 ninv, ninv_s;
         int pb, prefix;
     };
     static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
-        return K{D.q, 2 * D.q, D.tw, D.twi, pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix};
+        return K{D.q, 2 * D.q, as_global(D.tw), as_global(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix};
     }
-    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
-        const TwPair p = k.tw[idx];
-        ct_bfly(X, Y, p.w, p.ws, k.q, k.q2);
+    // twiddles: TwRaw is what a load brings from HBM/L2, TwReg what a butterfly consumes (prep() converts, once per twiddle)
+    typedef TwPair TwRaw;
+    typedef TwPair TwReg;
+    static constexpr bool PREFETCH = false;  // 16-byte raw twiddles: a second layer in flight does not fit 128 VGPRs
+    template <bool INV>
+    static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
+        const FHE_GLOBAL TwPair *p = (INV ? k.twi : k.tw) + idx;
+        TwRaw r;
+        r.w = p->w; r.ws = p->ws;
+        return r;
     }
+    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return r; }
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &p, const K &k) { ct_bfly(X, Y, p.w, p.ws, k.q, k.q2); }
     template <int PH>
-    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
-        const TwPair p = k.twi[idx];
-        gs_bfly(X, Y, p.w, p.ws, k.q, k.q2);
-    }
+    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &p, const K &k) { gs_bfly(X, Y, p.w, p.ws, k.q, k.q2); }
     static constexpr bool GS_FOLDS = false;
-    static constexpr bool JIT_TWIDDLES = true;
     static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
@@ -78,9 +92,12 @@ struct ArithShoup {
 //     w y = v + u c (mod q),   v = z0 + (z1 mod 2^31) 2^(B-31),   u = wh2 y1 + (z1 >> 31) < 2^63 + 2^33,
 // followed by one fold of the 96-bit v + u c at bit B.  8 multiply-adds + 5 other instructions, no compare/select, no
 // companion table.  Result < 2^B + 2^(63 + 2k - B) <= 1.25 * 2^B   (k = bits of c).
-struct PmTw {  // one twiddle, 16 bytes
+struct PmTw {  // one twiddle as a butterfly consumes it (registers only)
     unsigned wl, wlp, wh, wh2;
 };
+// In memory a twiddle is 8 bytes {wl, wh}; wlp and wh2 are two shifts, done once per loaded twiddle (a twiddle serves
+// 2..16 butterflies of a thread), so a layer's twiddles can be fetched one layer AHEAD without outgrowing 128 VGPRs.
+typedef uint2 PmRaw;
 struct PmK {
     u64 q, q2, q4;
     unsigned c;
@@ -115,10 +132,26 @@ struct ArithPM {
     static constexpr u64 MASK = (u64(1) << B) - 1;
     struct K {
         PmK m;
-        const PmTw *tw, *twi;
+        const FHE_GLOBAL PmRaw *tw, *twi;
         PmTw ninv;  // n^-1 (or 1) in twiddle form
         int pb, prefix;
     };
+    typedef PmRaw TwRaw;
+    typedef PmTw TwReg;
+    // One-unit-ahead twiddle prefetch in ntt14.hpp: measured 0.446 / 0.448 ms (fwd / inv, 4096 transforms) against 0.443 /
+    // 0.441 ms for just-in-time loads -- the two extra buffers push the kernel to 10 spilled VGPRs whose scratch traffic
+    // (+15 % HBM bytes) eats the hidden latency.  Off; tools/ntt_lab.hip keeps the variant.
+    static constexpr bool PREFETCH = false;
+    // memory form of twiddle w: low word wl = w mod 2^(B-31), high word wh = w >> (B-31)
+    static __host__ __device__ __forceinline__ u64 pack(u64 w) { return ((w >> (B - 31)) << 32) | (w & ((u64(1) << (B - 31)) - 1)); }
+    template <bool INV>
+    static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
+        const FHE_GLOBAL PmRaw *p = (INV ? k.twi : k.tw) + idx;
+        TwRaw r;
+        r.x = p->x; r.y = p->y;
+        return r;
+    }
+    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return PmTw{r.x, r.x << (63 - B), r.y, r.y << 1}; }
     static __host__ __device__ __forceinline__ PmTw split(u64 w) {
         PmTw t;
         t.wl = (unsigned)(w & ((u64(1) << (B - 31)) - 1));
@@ -131,7 +164,7 @@ struct ArithPM {
         K k;
         k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
         k.m.c = D.pm_c;
-        k.tw = reinterpret_cast<const PmTw *>(D.tww); k.twi = reinterpret_cast<const PmTw *>(D.twwi);
+        k.tw = (const FHE_GLOBAL PmRaw *)D.tww; k.twi = (const FHE_GLOBAL PmRaw *)D.twwi;
         k.ninv = split(pb ? 1 : D.ninv[log_n_total]);
         k.pb = pb; k.prefix = prefix;
         return k;
@@ -140,8 +173,8 @@ struct ArithPM {
     static __device__ __forceinline__ u64 fold1(u64 x, const PmK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
     // Forward butterfly without any reduction.  Values grow by at most 2q per layer; a multiplicand must stay below 2^63
     // and a sum below 2^64, which holds for 4 layers after a fold (inputs < q + eps -> multiplicands < 7q, outputs < 9q).
-    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
-        const u64 t = pm_mul<B>(Y, k.tw[idx], k.m);
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &w, const K &k) {
+        const u64 t = pm_mul<B>(Y, w, k.m);
         const u64 x = X;
         X = x + t;
         Y = x - t + k.m.q2;
@@ -150,14 +183,13 @@ struct ArithPM {
     // PH = 1 takes those (outputs: sum < 4q +, product < q +); the sums of a PH = 1 layer are folded (gs_fold) before the
     // next pair.
     template <int PH>
-    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
+    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &w, const K &k) {
         const u64 s = X + Y;
         const u64 d = X - Y + (PH ? k.m.q4 : k.m.q2);
         X = s;
-        Y = pm_mul<B>(d, k.twi[idx], k.m);
+        Y = pm_mul<B>(d, w, k.m);
     }
     static constexpr bool GS_FOLDS = true;
-    static constexpr bool JIT_TWIDDLES = true;
     // forward layers between two folds: inputs < q + eps, a multiplicand of layer L is < (2L - 1) q and must be < 2^63
     static constexpr int CT_LAYERS = ((1 << (63 - B)) + 1) / 2 > 64 ? 64 : ((1 << (63 - B)) + 1) / 2;
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }
@@ -178,51 +210,120 @@ struct ArithPM {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// radix-2^R butterfly networks on x[OFF .. OFF + 2^R): layers L0 .. L0+R-1 of a (sub-)transform
+// radix-2^R butterfly networks in registers, one reference layer (util/src/ring/fft.rs:40-77) at a time.
+//
+// A "unit" = one layer l of a radix-2^R network (layers L0 .. L0+R-1 of the sub-transform) applied to NREP replicas of the
+// network that sit STRIDE registers apart.  SHARED: every replica has the same block prefix `top` (they differ in a bit
+// BELOW the network), so 2^l twiddles serve all of them; otherwise replica rep has prefix top | rep << REP_SHIFT and its own
+// 2^l twiddles.  tw_load() fetches a unit's twiddles, ct_apply()/gs_apply() run its butterflies: kernels that can afford the
+// registers (A::PREFETCH) issue tw_load for the NEXT unit before ct_apply of the current one, so the L2 latency of a twiddle
+// fetch hides behind a layer of butterflies instead of stalling every wave of the workgroup at every layer.
 // ---------------------------------------------------------------------------------------------------------
+#define FHE_SCHED_FENCE() asm volatile("" ::: "memory")
+
+template <int L0_, int R_, int l_, int REP0_, int NREP_, int STRIDE_, bool SHARED_, int REP_SHIFT_ = 0>
+struct Unit {
+    static constexpr int L0 = L0_, R = R_, l = l_, REP0 = REP0_, NREP = NREP_, STRIDE = STRIDE_, REP_SHIFT = REP_SHIFT_;
+    static constexpr bool SHARED = SHARED_;
+    static constexpr int NT = (SHARED_ ? 1 : NREP_) << l_;  // twiddles of the unit
+    static constexpr int half = 1 << (R_ - 1 - l_);
+};
+
+template <class A, bool INV, class U, int NTW>
+__device__ __forceinline__ void tw_load(typename A::TwRaw (&raw)[NTW], int top, const typename A::K &k) {
+    static_assert(U::NT <= NTW, "twiddle buffer too small for this unit");
+#pragma unroll
+    for (int rr = 0; rr < (U::SHARED ? 1 : U::NREP); ++rr)
+#pragma unroll
+        for (int b = 0; b < (1 << U::l); ++b) {
+            const int tp = U::SHARED ? top : (top | ((U::REP0 + rr) << U::REP_SHIFT));
+            const int idx = (1 << (U::L0 + U::l + k.pb)) + ((((k.prefix << U::L0) | tp)) << U::l) + b;
+            raw[(rr << U::l) | b] = A::template fetch<INV>(k, idx);
+        }
+}
+
+template <class A, class U, int NTW, int E>
+__device__ __forceinline__ void ct_apply(u64 (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
+    // lazy policies bound how many layers may run between two folds (multiplicands must stay below 2^63)
+    if constexpr (U::l > 0 && U::l % A::CT_LAYERS == 0) {
+#pragma unroll
+        for (int rr = 0; rr < U::NREP; ++rr)
+#pragma unroll
+            for (int r = 0; r < (1 << U::R); ++r) x[(U::REP0 + rr) * U::STRIDE + r] = A::fold(x[(U::REP0 + rr) * U::STRIDE + r], k);
+    }
+    if constexpr (U::SHARED) {
+#pragma unroll
+        for (int b = 0; b < (1 << U::l); ++b) {
+            const typename A::TwReg w = A::prep(raw[b]);
+#pragma unroll
+            for (int rr = 0; rr < U::NREP; ++rr)
+#pragma unroll
+                for (int j = 0; j < U::half; ++j) {
+                    const int o = (U::REP0 + rr) * U::STRIDE + b * 2 * U::half + j;
+                    A::ct(x[o], x[o + U::half], w, k);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < U::NREP; ++rr)
+#pragma unroll
+            for (int b = 0; b < (1 << U::l); ++b) {
+                const typename A::TwReg w = A::prep(raw[(rr << U::l) | b]);
+#pragma unroll
+                for (int j = 0; j < U::half; ++j) {
+                    const int o = (U::REP0 + rr) * U::STRIDE + b * 2 * U::half + j;
+                    A::ct(x[o], x[o + U::half], w, k);
+                }
+            }
+    }
+}
+
+// inverse: the unit of layer l is step R-1-l of its network; PH = step & 1 pairs layers for the lazy policies, sums are
+// folded after every second layer and after the last layer of a network with an odd layer count
+template <class A, class U, int NTW, int E>
+__device__ __forceinline__ void gs_apply(u64 (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
+    constexpr int step = U::R - 1 - U::l, PH = step & 1;
+    constexpr bool FOLD = A::GS_FOLDS && (PH == 1 || step == U::R - 1);
+    static_for<0, (U::SHARED ? (1 << U::l) : U::NREP)>([&](auto oc) {
+        constexpr int outer = decltype(oc)::value;
+        static_for<0, (U::SHARED ? U::NREP : (1 << U::l))>([&](auto ic) {
+            constexpr int inner = decltype(ic)::value;
+            constexpr int b = U::SHARED ? outer : inner, rr = U::SHARED ? inner : outer;
+            const typename A::TwReg w = A::prep(raw[U::SHARED ? b : ((rr << U::l) | b)]);
+#pragma unroll
+            for (int j = 0; j < U::half; ++j) {
+                const int o = (U::REP0 + rr) * U::STRIDE + b * 2 * U::half + j;
+                A::template gs<PH>(x[o], x[o + U::half], w, k);
+                if constexpr (FOLD) x[o] = A::gs_fold(x[o], k);
+            }
+        });
+    });
+}
+
+// one whole network with just-in-time twiddles (a layer's loads stay inside that layer): the generic kernels, the
+// 2^15..2^17 passes and the wave-per-ciphertext FHEW kernels
 template <class A, int L0, int R, int OFF, int E>
 __device__ __forceinline__ void ct_net(u64 (&x)[E], int top, const typename A::K &k) {
-#pragma unroll
-    for (int l = 0; l < R; ++l) {
-        const int half = 1 << (R - 1 - l);
-        // keep the twiddle loads of a layer inside that layer: hoisting all 2^R - 1 of them to the top of the pass costs
-        // more registers than the kernel has (two workgroups per CU leave 128 VGPRs per thread)
-        if (A::JIT_TWIDDLES && l > 0) asm volatile("" ::: "memory");
-        // lazy policies bound how many layers may run between two folds (multiplicands must stay below 2^63)
-        if (l > 0 && l % A::CT_LAYERS == 0) {
-#pragma unroll
-            for (int r = 0; r < (1 << R); ++r) x[OFF + r] = A::fold(x[OFF + r], k);
-        }
-#pragma unroll
-        for (int b = 0; b < (1 << l); ++b) {
-            const int idx = (1 << (L0 + l + k.pb)) + ((((k.prefix << L0) | top)) << l) + b;
-#pragma unroll
-            for (int j = 0; j < half; ++j) A::ct(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], idx, k);
-        }
-    }
+    static_for<0, R>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        typedef Unit<L0, R, l, 1, 1, OFF, true> U;  // one replica at register offset REP0 * STRIDE = OFF
+        if constexpr (l > 0) FHE_SCHED_FENCE();
+        typename A::TwRaw raw[1 << l];
+        tw_load<A, false, U>(raw, top, k);
+        ct_apply<A, U>(x, raw, k);
+    });
 }
 
 template <class A, int L0, int R, int OFF, int E>
 __device__ __forceinline__ void gs_net(u64 (&x)[E], int top, const typename A::K &k) {
-    static_for<0, R>([&](auto step_c) {
-        constexpr int step = decltype(step_c)::value;  // 0 .. R-1, layer l = R-1-step
-        constexpr int l = R - 1 - step;
-        constexpr int PH = step & 1;
-        constexpr int half = 1 << (R - 1 - l);
-        if (A::JIT_TWIDDLES && step > 0) asm volatile("" ::: "memory");
-#pragma unroll
-        for (int b = 0; b < (1 << l); ++b) {
-            const int idx = (1 << (L0 + l + k.pb)) + ((((k.prefix << L0) | top)) << l) + b;
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                A::template gs<PH>(x[OFF + b * 2 * half + j], x[OFF + b * 2 * half + j + half], idx, k);
-                // sums are folded after every second layer, and after the last layer of a network with an odd layer count,
-                // so that every network starts from values < q + eps
-                if constexpr (A::GS_FOLDS && (PH == 1 || step == R - 1)) x[OFF + b * 2 * half + j] = A::gs_fold(x[OFF + b * 2 * half + j], k);
-            }
-        }
+    static_for<0, R>([&](auto sc) {
+        constexpr int l = R - 1 - decltype(sc)::value;
+        typedef Unit<L0, R, l, 1, 1, OFF, true> U;
+        if constexpr (l < R - 1) FHE_SCHED_FENCE();
+        typename A::TwRaw raw[1 << l];
+        tw_load<A, true, U>(raw, top, k);
+        gs_apply<A, U>(x, raw, k);
     });
 }
-
 
 }  // namespace fhe

@@ -236,9 +236,45 @@ __device__ unsigned long long g_stamps[4096][16];
 // ---------------------------------------------------------------------------------------------------------
 // kernels: one workgroup = one (sub-)polynomial of 2^14 coefficients; sub s of polynomial s >> pb
 // ---------------------------------------------------------------------------------------------------------
+// The 14 layers are 16 units (arith.hpp): passes 0..2 are four units of 2 replicas (the passive bit) sharing twiddles, pass 3
+// is two layers on 8 replicas with their own twiddles, taken 4 replicas at a time.  Unit u's butterflies run while unit
+// u+1's twiddles are in flight (policies with PREFETCH; otherwise each unit fetches its own just in time), across the
+// exchanges too: the first unit of a pass is fetched before the exchange that precedes it.
+namespace n14 {
+template <int l> using P0 = Unit<0, 4, l, 0, 2, 16, true>;
+template <int l> using P1 = Unit<4, 4, l, 0, 2, 16, true>;
+template <int l> using P2 = Unit<8, 4, l, 0, 2, 16, true>;
+template <int l, int H> using P3 = Unit<12, 2, l, 4 * H, 4, 4, false, 9>;  // replica s3: block prefix (s3 << 9) | t
+
+// forward step: (prefetch NEXT's twiddles | fetch CUR's), then CUR's butterflies
+template <class A, class CUR, class NEXT>
+__device__ __forceinline__ void fstep(u64 (&x)[32], typename A::TwRaw (&cur)[8], typename A::TwRaw (&next)[8], int top_cur, int top_next,
+                                      const typename A::K &k) {
+    FHE_SCHED_FENCE();
+    if constexpr (A::PREFETCH) {
+        if constexpr (!std::is_void<NEXT>::value) tw_load<A, false, NEXT>(next, top_next, k);
+    } else {
+        tw_load<A, false, CUR>(cur, top_cur, k);
+    }
+    ct_apply<A, CUR>(x, cur, k);
+}
+template <class A, class CUR, class NEXT>
+__device__ __forceinline__ void istep(u64 (&x)[32], typename A::TwRaw (&cur)[8], typename A::TwRaw (&next)[8], int top_cur, int top_next,
+                                      const typename A::K &k) {
+    FHE_SCHED_FENCE();
+    if constexpr (A::PREFETCH) {
+        if constexpr (!std::is_void<NEXT>::value) tw_load<A, true, NEXT>(next, top_next, k);
+    } else {
+        tw_load<A, true, CUR>(cur, top_cur, k);
+    }
+    gs_apply<A, CUR>(x, cur, k);
+}
+}  // namespace n14
+
 template <class A>
 __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                     unsigned n_desc, unsigned subs, int pb) {
+    using namespace n14;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x;
@@ -247,7 +283,10 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restri
     const typename A::K k = A::make(D, 14, pb, int(sub & ((1u << pb) - 1)));
     u64 *g = data + (size_t(sub) << 14);
     u64 x[32];
+    typename A::TwRaw ta[8], tb[8];
+    const int t1 = t >> 5, t2 = t >> 1;  // block prefixes of passes 1 and 2; pass 3: (s3 << 9) | t
     STAMP(0);
+    if constexpr (A::PREFETCH) tw_load<A, false, P0<0>>(ta, 0, k);
     // pass 0: layers 0..3
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = g[((r & 15) << 10) | ((r >> 4) << 9) | t];
@@ -255,34 +294,40 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     STAMP(1);
-    ct_net<A, 0, 4, 0, 32>(x, 0, k);
-    ct_net<A, 0, 4, 16, 32>(x, 0, k);
+    fstep<A, P0<0>, P0<1>>(x, ta, tb, 0, 0, k);
+    fstep<A, P0<1>, P0<2>>(x, tb, ta, 0, 0, k);
+    fstep<A, P0<2>, P0<3>>(x, ta, tb, 0, 0, k);
+    fstep<A, P0<3>, P1<0>>(x, tb, ta, 0, t1, k);
     STAMP(2);
     xchg_01(x, t, lds);
     STAMP(3);
     // pass 1: layers 4..7, block prefix = bits 13..10
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
-    ct_net<A, 4, 4, 0, 32>(x, t >> 5, k);
-    ct_net<A, 4, 4, 16, 32>(x, t >> 5, k);
+    fstep<A, P1<0>, P1<1>>(x, ta, tb, t1, t1, k);
+    fstep<A, P1<1>, P1<2>>(x, tb, ta, t1, t1, k);
+    fstep<A, P1<2>, P1<3>>(x, ta, tb, t1, t1, k);
+    fstep<A, P1<3>, P2<0>>(x, tb, ta, t1, t2, k);
     STAMP(4);
     xchg_12(x, t, lds);
     STAMP(5);
     // pass 2: layers 8..11, block prefix = bits 13..6
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
-    ct_net<A, 8, 4, 0, 32>(x, t >> 1, k);
-    ct_net<A, 8, 4, 16, 32>(x, t >> 1, k);
+    fstep<A, P2<0>, P2<1>>(x, ta, tb, t2, t2, k);
+    fstep<A, P2<1>, P2<2>>(x, tb, ta, t2, t2, k);
+    fstep<A, P2<2>, P2<3>>(x, ta, tb, t2, t2, k);
+    fstep<A, P2<3>, P3<0, 0>>(x, tb, ta, t2, t, k);
     STAMP(6);
     xchg_23(x, t, lds);
     STAMP(7);
     // pass 3: layers 12..13, block prefix = bits 13..2 = (s3 << 9) | t
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
-    static_for<0, 8>([&](auto s3c) {
-        constexpr int s3 = decltype(s3c)::value;
-        ct_net<A, 12, 2, 4 * s3, 32>(x, (s3 << 9) | t, k);
-    });
+    fstep<A, P3<0, 0>, P3<1, 0>>(x, ta, tb, t, t, k);
+    fstep<A, P3<1, 0>, P3<0, 1>>(x, tb, ta, t, t, k);
+    fstep<A, P3<0, 1>, P3<1, 1>>(x, ta, tb, t, t, k);
+    fstep<A, P3<1, 1>, void>(x, tb, ta, t, t, k);
     STAMP(8);
 #pragma unroll
     for (int s3 = 0; s3 < 8; ++s3) {
@@ -302,6 +347,7 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restri
 template <class A>
 __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                     unsigned n_desc, unsigned subs, int pb) {
+    using namespace n14;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x;
@@ -310,6 +356,9 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restri
     const typename A::K k = A::make(D, 14, pb, int(sub & ((1u << pb) - 1)));
     u64 *g = data + (size_t(sub) << 14);
     u64 x[32];
+    typename A::TwRaw ta[8], tb[8];
+    const int t1 = t >> 5, t2 = t >> 1;
+    if constexpr (A::PREFETCH) tw_load<A, true, P3<1, 0>>(ta, t, k);
     // pass 3: layers 13..12
 #pragma unroll
     for (int s3 = 0; s3 < 8; ++s3) {
@@ -317,19 +366,25 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restri
         const ulonglong2 lo = src[0], hi = src[1];
         x[4 * s3 + 0] = lo.x; x[4 * s3 + 1] = lo.y; x[4 * s3 + 2] = hi.x; x[4 * s3 + 3] = hi.y;
     }
-    static_for<0, 8>([&](auto s3c) {
-        constexpr int s3 = decltype(s3c)::value;
-        gs_net<A, 12, 2, 4 * s3, 32>(x, (s3 << 9) | t, k);
-    });
+    istep<A, P3<1, 0>, P3<0, 0>>(x, ta, tb, t, t, k);
+    istep<A, P3<0, 0>, P3<1, 1>>(x, tb, ta, t, t, k);
+    istep<A, P3<1, 1>, P3<0, 1>>(x, ta, tb, t, t, k);
+    istep<A, P3<0, 1>, P2<3>>(x, tb, ta, t, t2, k);
     xchg_32(x, t, lds);
-    gs_net<A, 8, 4, 0, 32>(x, t >> 1, k);
-    gs_net<A, 8, 4, 16, 32>(x, t >> 1, k);
+    istep<A, P2<3>, P2<2>>(x, ta, tb, t2, t2, k);
+    istep<A, P2<2>, P2<1>>(x, tb, ta, t2, t2, k);
+    istep<A, P2<1>, P2<0>>(x, ta, tb, t2, t2, k);
+    istep<A, P2<0>, P1<3>>(x, tb, ta, t2, t1, k);
     xchg_21(x, t, lds);
-    gs_net<A, 4, 4, 0, 32>(x, t >> 5, k);
-    gs_net<A, 4, 4, 16, 32>(x, t >> 5, k);
+    istep<A, P1<3>, P1<2>>(x, ta, tb, t1, t1, k);
+    istep<A, P1<2>, P1<1>>(x, tb, ta, t1, t1, k);
+    istep<A, P1<1>, P1<0>>(x, ta, tb, t1, t1, k);
+    istep<A, P1<0>, P0<3>>(x, tb, ta, t1, 0, k);
     xchg_10(x, t, lds);
-    gs_net<A, 0, 4, 0, 32>(x, 0, k);
-    gs_net<A, 0, 4, 16, 32>(x, 0, k);
+    istep<A, P0<3>, P0<2>>(x, ta, tb, 0, 0, k);
+    istep<A, P0<2>, P0<1>>(x, tb, ta, 0, 0, k);
+    istep<A, P0<1>, P0<0>>(x, ta, tb, 0, 0, k);
+    istep<A, P0<0>, void>(x, tb, ta, 0, 0, k);
 #pragma unroll
     for (int r = 0; r < 32; ++r) g[((r & 15) << 10) | ((r >> 4) << 9) | t] = A::finish_inv(x[r], k);
 }

@@ -61,16 +61,16 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
         case 11: return launch_gen<A, 11, 4, 2>(inv, d, nd, a, subs, 0, st);
         case 12: return launch_gen<A, 12, 4, 1>(inv, d, nd, a, subs, 0, st);
         case 13: return launch_gen<A, 13, 4, 1>(inv, d, nd, a, subs, 0, st);
-        case 14: return pb ? launch_gen<A, 14, 4, 1, true>(inv, d, nd, a, subs, pb, st) : launch_gen<A, 14, 4, 1, false>(inv, d, nd, a, subs, 0, st);
         default: return FHE_ERR_UNSUPPORTED;
     }
 }
 
-// N = 2^14 inverse with pseudo-Mersenne arithmetic: the register-resident kernel of ntt14.hpp measured faster than the
-// LDS-resident one (0.49 vs 0.56 ms for 4096 transforms; the forward direction is the other way round)
+// N = 2^14 (and the 2^14 sub-transforms of larger rings): the register-resident kernels of ntt14.hpp, two workgroups per
+// CU; measured faster than the LDS-resident generic kernel in both directions and for both arithmetic policies
+// (tools/ntt_lab.hip: 0.446 / 0.448 ms against 0.486 / 0.481 ms for 4096 pseudo-Mersenne transforms)
 template <class A>
-int launch14_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
-    auto k = fhe::ntt14_inv_kernel<A>;
+int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
+    auto k = inv ? fhe::ntt14_inv_kernel<A> : fhe::ntt14_fwd_kernel<A>;
     HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fhe::N14_LDS_BYTES));
     hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::N14_THREADS), fhe::N14_LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());
@@ -81,11 +81,12 @@ int launch14_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
     if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st);
-    if (pm == 60) return (inv && log_n == 14) ? launch14_inv<fhe::ArithPM<60>>(d, nd, a, subs, pb, st)
-                                              : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st);
-    if (pm == 54) return (inv && log_n == 14) ? launch14_inv<fhe::ArithPM<54>>(d, nd, a, subs, pb, st)
-                                              : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st);
-    return dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st);
+    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st)
+                                     : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st);
+    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st)
+                                     : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st);
+    return log_n == 14 ? launch14<fhe::ArithShoup>(inv, d, nd, a, subs, pb, st)
+                       : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st);
 }
 int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
     return sub_transform(false, d, nd, a, log_n, subs, pb, pm, st);
@@ -223,22 +224,15 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
         if (e == hipSuccess) e = hipMemcpy(c->d_tw, pf.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->d_twi, pi.data(), cap * sizeof(fhe::TwPair), hipMemcpyHostToDevice);
         if (e == hipSuccess && c->pm_b) {
-            // twiddles in the 16-byte form ntt14.hpp's pm_mul reads: {wl, wl << (63-b), wh, 2 wh}, w = wl + wh 2^(b-31)
+            // twiddles in the 8-byte form the pseudo-Mersenne policy loads: {wl, wh}, w = wl + wh 2^(b-31) (arith.hpp PmRaw)
             const int b = c->pm_b;
-            std::vector<fhe::PmTw> lf(cap), li(cap);
-            auto split = [b](uint64_t w) {
-                fhe::PmTw t;
-                t.wl = (unsigned)(w & ((uint64_t(1) << (b - 31)) - 1));
-                t.wlp = t.wl << (63 - b);
-                t.wh = (unsigned)(w >> (b - 31));
-                t.wh2 = t.wh << 1;
-                return t;
-            };
-            for (size_t j = 0; j < cap; ++j) { lf[j] = split(c->tw[j]); li[j] = split(c->twi[j]); }
-            e = hipMalloc((void **)&c->d_tww, 2 * cap * sizeof(fhe::PmTw));
-            c->d_twwi = c->d_tww + 2 * cap;  // u64 units: one PmTw = 2 words
-            if (e == hipSuccess) e = hipMemcpy(c->d_tww, lf.data(), cap * sizeof(fhe::PmTw), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(c->d_twwi, li.data(), cap * sizeof(fhe::PmTw), hipMemcpyHostToDevice);
+            std::vector<uint64_t> lf(cap), li(cap);
+            auto pack = [b](uint64_t w) { return ((w >> (b - 31)) << 32) | (w & ((uint64_t(1) << (b - 31)) - 1)); };
+            for (size_t j = 0; j < cap; ++j) { lf[j] = pack(c->tw[j]); li[j] = pack(c->twi[j]); }
+            e = hipMalloc((void **)&c->d_tww, 2 * cap * sizeof(uint64_t));
+            c->d_twwi = c->d_tww + cap;
+            if (e == hipSuccess) e = hipMemcpy(c->d_tww, lf.data(), cap * sizeof(uint64_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->d_twwi, li.data(), cap * sizeof(uint64_t), hipMemcpyHostToDevice);
         }
         c->h_desc.tww = c->d_tww;
         c->h_desc.twwi = c->d_twwi;

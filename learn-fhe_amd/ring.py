@@ -206,6 +206,17 @@ def rlwe_sample_extract(q, ct_a, ct_b, n, index, addend=0):
     return out_a, out_b
 
 
+def ak_t(n, w, g=5):
+    """scheme/fhew/src/bootstrapping.rs:86-89: the automorphism exponents [-g, g, g^2 .. g^w] mod 2N as signed values."""
+    q2 = 2 * n
+    c = lambda v: v - q2 if v >= q2 // 2 else v  # noqa: E731  Zq -> i64 (centered, util/src/zq.rs:240-249)
+    out, x = [c((q2 - g) % q2)], 1
+    for _ in range(w):
+        x = x * g % q2
+        out.append(c(x))
+    return out
+
+
 class BootstrapKey:
     """scheme/fhew/src/bootstrapping.rs:93-113 (brk + ak part)."""
 

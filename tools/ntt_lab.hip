@@ -9,26 +9,19 @@
 using namespace fhe;
 // ablation policies for the ntt14 structure
 struct ArithNone : ArithPM<60> {  // exchanges + HBM traffic only
-    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int, const K &) { X ^= 1; Y ^= 1; }
-    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int, const K &) { X ^= 1; Y ^= 1; }
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
+    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
+    template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &, int idx) { return TwRaw{(unsigned)idx, 1u}; }
     static constexpr bool GS_FOLDS = false;
     static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &) { return x; }
 };
-struct ArithNoTw : ArithPM<60> {  // butterflies with a register-resident twiddle: no twiddle loads
-    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, int idx, const K &k) {
-        PmTw w = k.ninv; w.wl += idx;
-        const u64 t = pm_mul<60>(Y, w, k.m);
-        const u64 x = X;
-        X = x + t; Y = x - t + k.m.q2;
-    }
-    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, int idx, const K &k) {
-        PmTw w = k.ninv; w.wl += idx;
-        const u64 s = X + Y;
-        const u64 d = X - Y + (PH ? k.m.q4 : k.m.q2);
-        X = s; Y = pm_mul<60>(d, w, k.m);
-    }
+struct ArithNoTw : ArithPM<60> {  // butterflies with a computed twiddle: no twiddle loads
+    template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) { return TwRaw{k.ninv.wl + (unsigned)idx, k.ninv.wh}; }
+};
+struct ArithPrefetch : ArithPM<60> {  // the same arithmetic with the one-unit-ahead twiddle prefetch
+    static constexpr bool PREFETCH = true;
 };
 #ifndef LAB_LOG_N
 #define LAB_LOG_N 14
@@ -81,12 +74,12 @@ int main(int argc, char **argv) {
     hd.q = q; hd.tw = d_tw; hd.twi = d_twi; hd.one_s = shoup(1, q);
     for (int k = 0; k < 20; ++k) { hd.ninv[k] = invmod((u64(1) << k) % q, q); hd.ninv_s[k] = shoup(hd.ninv[k], q); }
     {   // pseudo-Mersenne tables (q = 2^60 - 98303)
-        std::vector<PmTw> w(cap), wi(cap);
-        for (size_t j = 0; j < cap; ++j) { w[j] = ArithPM<60>::split(tw[j].w); wi[j] = ArithPM<60>::split(twi[j].w); }
-        PmTw *dw, *dwi;
-        hipMalloc(&dw, cap * sizeof(PmTw)); hipMalloc(&dwi, cap * sizeof(PmTw));
-        hipMemcpy(dw, w.data(), cap * sizeof(PmTw), hipMemcpyHostToDevice);
-        hipMemcpy(dwi, wi.data(), cap * sizeof(PmTw), hipMemcpyHostToDevice);
+        std::vector<u64> w(cap), wi(cap);
+        for (size_t j = 0; j < cap; ++j) { w[j] = ArithPM<60>::pack(tw[j].w); wi[j] = ArithPM<60>::pack(twi[j].w); }
+        u64 *dw, *dwi;
+        hipMalloc(&dw, cap * 8); hipMalloc(&dwi, cap * 8);
+        hipMemcpy(dw, w.data(), cap * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dwi, wi.data(), cap * 8, hipMemcpyHostToDevice);
         hd.tww = (const u64 *)dw; hd.twwi = (const u64 *)dwi; hd.pm_b = 60; hd.pm_c = (unsigned)((u64(1) << 60) - q);
     }
     ModDesc *d_desc;
@@ -106,6 +99,7 @@ int main(int argc, char **argv) {
         {"ntt14 pseudo-Mersenne", ntt14_fwd_kernel<ArithPM<60>>, ntt14_inv_kernel<ArithPM<60>>},
         {"ntt14 ablation: no butterflies", ntt14_fwd_kernel<ArithNone>, ntt14_inv_kernel<ArithNone>},
         {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw>, ntt14_inv_kernel<ArithNoTw>},
+        {"ntt14 pseudo-Mersenne, twiddle prefetch", ntt14_fwd_kernel<ArithPrefetch>, ntt14_inv_kernel<ArithPrefetch>},
     };
     Variant vars[] = {
         {"generic Shoup, fwd staged / inv direct", ntt_fwd_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, true>},

@@ -60,9 +60,9 @@ def find(kern, counter):
     return None
 
 
-fw_r, fw_w = find(("ntt_fwd_kernel<", " 14,"), "FETCH_SIZE"), find(("ntt_fwd_kernel<", " 14,"), "WRITE_SIZE")
+fw_r, fw_w = find(("ntt14_fwd_kernel<", "ArithPM<60>"), "FETCH_SIZE"), find(("ntt14_fwd_kernel<", "ArithPM<60>"), "WRITE_SIZE")
 if fw_r and fw_w:
-    json.dump({"source": "profiles/%s_pmc.json" % tag, "kernel": "ntt_fwd_kernel<ArithPM<60>, 14, 4, 1> (forward, batch 4096)",
+    json.dump({"source": "profiles/%s_pmc.json" % tag, "kernel": "ntt14_fwd_kernel<ArithPM<60>> (forward, batch 4096)",
                "ntt_fwd_read_bytes_per_launch": fw_r, "ntt_fwd_write_bytes_per_launch": fw_w,
                "ntt_fwd_bytes_per_launch": fw_r + fw_w,
                "correction": "FETCH_SIZE x2 (gfx950 reads 1/2, calibrated on copy8/copy16 of 512 MiB), WRITE_SIZE x1, KiB"},
