@@ -56,7 +56,7 @@ struct ArithShoup {
     // twiddles: TwRaw is what a load brings from HBM/L2, TwReg what a butterfly consumes (prep() converts, once per twiddle)
     typedef TwPair TwRaw;
     typedef TwPair TwReg;
-    static constexpr bool PREFETCH = false;  // 16-byte raw twiddles: a second layer in flight does not fit 128 VGPRs
+    static constexpr int PREFETCH = 0;  // largest twiddle set fetched one unit ahead (ntt14.hpp); 16-byte raw twiddles: none fits
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
         const FHE_GLOBAL TwPair *p = (INV ? k.twi : k.tw) + idx;
@@ -85,22 +85,23 @@ struct ArithShoup {
 // Pseudo-Mersenne product, q = 2^B - c (c < 2^(B-33), 34 <= B <= 60).
 // On gfx950 every integer VALU instruction costs about the same issue time (~16 lanes/clk/SIMD; v_mul_lo/hi_u32 twice
 // that), v_mad_u64_u32 included, so the product is arranged to need as FEW instructions as possible, all word aligned:
-// the fixed operand w is split at B-31 bits, w = wl + wh 2^(B-31) (wh < 2^31), and stored with wlp = wl << (63-B) and
-// wh2 = 2 wh, so that with y = y0 + y1 2^32 (any y < 2^63)
-//     w y = z0 + z1 2^(B-31) + wh y1 2^(B+1),  z0 = wl y0,  z1 = wh y0 + wlp y1 < 2^64 (no carry),  2^(B+1) = 2c,
-//     z1 2^(B-31) = (z1 >> 31) c + (z1 mod 2^31) 2^(B-31),
-//     w y = v + u c (mod q),   v = z0 + (z1 mod 2^31) 2^(B-31),   u = wh2 y1 + (z1 >> 31) < 2^63 + 2^33,
-// followed by one fold of the 96-bit v + u c at bit B.  8 multiply-adds + 5 other instructions, no compare/select, no
-// companion table.  Result < 2^B + 2^(63 + 2k - B) <= 1.25 * 2^B   (k = bits of c).
+// the fixed operand w is split at B-31 bits, w = wl + wh 2^(B-31) (wh < 2^31), and kept with wlp = wl << (63-B), so that
+// with y = y0 + y1 2^32 (any y < 2^63)
+//     w y = z0 + z1 2^(B-31) + wh y1 2^(B+1),  z0 = wl y0,  z1 = wh y0 + wlp y1 < 2^64 (no carry),
+//     z1 2^(B-31) = lo32(z1) 2^(B-31) + hi32(z1) 2^(B+1),            2^(B+1) = 2c (mod q),
+//     w y = v + u 2c (mod q),   v = z0 + lo32(z1) 2^(B-31) < 2^(B+2),   u = wh y1 + hi32(z1) < 2^62 + 2^32,
+// followed by one fold of the 96-bit v + u 2c at bit B.  8 multiply-adds + 4 other instructions (two of them only move a
+// high word into a zero-extended pair), no mask, no compare/select, no companion table.
+// Result < 2^B + 2^(64 + 2k - B) <= 1.25 * 2^B   (k = bits of c <= B - 33).
 struct PmTw {  // one twiddle as a butterfly consumes it (registers only)
-    unsigned wl, wlp, wh, wh2;
+    unsigned wl, wlp, wh;
 };
-// In memory a twiddle is 8 bytes {wl, wh}; wlp and wh2 are two shifts, done once per loaded twiddle (a twiddle serves
-// 2..16 butterflies of a thread), so a layer's twiddles can be fetched one layer AHEAD without outgrowing 128 VGPRs.
+// In memory a twiddle is 8 bytes {wl, wh}; wlp is one shift, done once per loaded twiddle (a twiddle serves 2..16
+// butterflies of a thread).
 typedef uint2 PmRaw;
 struct PmK {
     u64 q, q2, q4;
-    unsigned c;
+    unsigned c, c2;  // c and 2c
 };
 
 // a * b + c as ONE v_mad_u64_u32 even where the compiler would strength-reduce a power-of-two multiplier into a 64-bit
@@ -111,16 +112,23 @@ __device__ __forceinline__ u64 mad_u64(unsigned a, unsigned b, u64 c) {
     return d;
 }
 
+// x >> 32 as a 64-bit operand in ONE instruction (the compiler builds the zero-extended pair from two moves)
+__device__ __forceinline__ u64 hi_word(u64 x) {
+    u64 d;
+    asm("v_lshrrev_b64 %0, 32, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+
 template <int B>
 __device__ __forceinline__ u64 pm_mul(u64 y, const PmTw w, const PmK &k) {
-    constexpr unsigned M31 = 0x7fffffffu, HMASK = (1u << (B - 32)) - 1;
+    constexpr unsigned HMASK = (1u << (B - 32)) - 1;
     const unsigned y0 = (unsigned)y, y1 = (unsigned)(y >> 32);
     const u64 z0 = (u64)w.wl * y0;
     const u64 z1 = (u64)w.wh * y0 + (u64)w.wlp * y1;
-    const u64 v = mad_u64((unsigned)z1 & M31, 1u << (B - 31), z0);
-    const u64 u = (u64)w.wh2 * y1 + (z1 >> 31);
-    const u64 r1 = (u64)(unsigned)u * k.c + v;
-    const u64 r2 = (u64)(unsigned)(u >> 32) * k.c + (r1 >> 32);  // v + u c = r2 * 2^32 + lo32(r1)
+    const u64 v = mad_u64((unsigned)z1, 1u << (B - 31), z0);
+    const u64 u = (u64)w.wh * y1 + hi_word(z1);
+    const u64 r1 = (u64)(unsigned)u * k.c2 + v;
+    const u64 r2 = (u64)(unsigned)(u >> 32) * k.c2 + (r1 >> 32);  // v + u 2c = r2 * 2^32 + lo32(r1)
     const unsigned h2 = (unsigned)(r2 >> (B - 32));
     const u64 l2 = ((u64)((unsigned)r2 & HMASK) << 32) | (unsigned)r1;
     return (u64)h2 * k.c + l2;
@@ -138,10 +146,10 @@ struct ArithPM {
     };
     typedef PmRaw TwRaw;
     typedef PmTw TwReg;
-    // One-unit-ahead twiddle prefetch in ntt14.hpp: measured 0.446 / 0.448 ms (fwd / inv, 4096 transforms) against 0.443 /
-    // 0.441 ms for just-in-time loads -- the two extra buffers push the kernel to 10 spilled VGPRs whose scratch traffic
-    // (+15 % HBM bytes) eats the hidden latency.  Off; tools/ntt_lab.hip keeps the variant.
-    static constexpr bool PREFETCH = false;
+    // ntt14.hpp fetches twiddle sets of up to PREFETCH entries one unit ahead of their butterflies.  Measured (4096
+    // transforms, tools/ntt_lab.hip): none 0.436 / 0.444 ms (fwd / inv), <= 2: 0.430 / 0.445, <= 4: 0.412 / 0.435, all (8):
+    // 0.433 / 0.444 -- the 8-entry sets push the kernel into 12 spilled VGPRs whose scratch traffic eats the hidden latency.
+    static constexpr int PREFETCH = 4;
     // memory form of twiddle w: low word wl = w mod 2^(B-31), high word wh = w >> (B-31)
     static __host__ __device__ __forceinline__ u64 pack(u64 w) { return ((w >> (B - 31)) << 32) | (w & ((u64(1) << (B - 31)) - 1)); }
     template <bool INV>
@@ -151,19 +159,18 @@ struct ArithPM {
         r.x = p->x; r.y = p->y;
         return r;
     }
-    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return PmTw{r.x, r.x << (63 - B), r.y, r.y << 1}; }
+    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return PmTw{r.x, r.x << (63 - B), r.y}; }
     static __host__ __device__ __forceinline__ PmTw split(u64 w) {
         PmTw t;
         t.wl = (unsigned)(w & ((u64(1) << (B - 31)) - 1));
         t.wlp = t.wl << (63 - B);
         t.wh = (unsigned)(w >> (B - 31));
-        t.wh2 = t.wh << 1;
         return t;
     }
     static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
         K k;
         k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
-        k.m.c = D.pm_c;
+        k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c;
         k.tw = (const FHE_GLOBAL PmRaw *)D.tww; k.twi = (const FHE_GLOBAL PmRaw *)D.twwi;
         k.ninv = split(pb ? 1 : D.ninv[log_n_total]);
         k.pb = pb; k.prefix = prefix;

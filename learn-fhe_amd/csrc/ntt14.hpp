@@ -246,15 +246,18 @@ template <int l> using P1 = Unit<4, 4, l, 0, 2, 16, true>;
 template <int l> using P2 = Unit<8, 4, l, 0, 2, 16, true>;
 template <int l, int H> using P3 = Unit<12, 2, l, 4 * H, 4, 4, false, 9>;  // replica s3: block prefix (s3 << 9) | t
 
+// is unit U's twiddle set fetched one unit ahead?  (policies bound the size of a prefetched set: registers)
+template <class A, class U>
+__device__ constexpr bool ahead() { return A::PREFETCH > 0 && U::NT <= A::PREFETCH; }
+
 // forward step: (prefetch NEXT's twiddles | fetch CUR's), then CUR's butterflies
 template <class A, class CUR, class NEXT>
 __device__ __forceinline__ void fstep(u64 (&x)[32], typename A::TwRaw (&cur)[8], typename A::TwRaw (&next)[8], int top_cur, int top_next,
                                       const typename A::K &k) {
     FHE_SCHED_FENCE();
-    if constexpr (A::PREFETCH) {
-        if constexpr (!std::is_void<NEXT>::value) tw_load<A, false, NEXT>(next, top_next, k);
-    } else {
-        tw_load<A, false, CUR>(cur, top_cur, k);
+    if constexpr (!ahead<A, CUR>()) tw_load<A, false, CUR>(cur, top_cur, k);
+    if constexpr (!std::is_void<NEXT>::value) {
+        if constexpr (ahead<A, NEXT>()) tw_load<A, false, NEXT>(next, top_next, k);
     }
     ct_apply<A, CUR>(x, cur, k);
 }
@@ -262,31 +265,22 @@ template <class A, class CUR, class NEXT>
 __device__ __forceinline__ void istep(u64 (&x)[32], typename A::TwRaw (&cur)[8], typename A::TwRaw (&next)[8], int top_cur, int top_next,
                                       const typename A::K &k) {
     FHE_SCHED_FENCE();
-    if constexpr (A::PREFETCH) {
-        if constexpr (!std::is_void<NEXT>::value) tw_load<A, true, NEXT>(next, top_next, k);
-    } else {
-        tw_load<A, true, CUR>(cur, top_cur, k);
+    if constexpr (!ahead<A, CUR>()) tw_load<A, true, CUR>(cur, top_cur, k);
+    if constexpr (!std::is_void<NEXT>::value) {
+        if constexpr (ahead<A, NEXT>()) tw_load<A, true, NEXT>(next, top_next, k);
     }
     gs_apply<A, CUR>(x, cur, k);
 }
 }  // namespace n14
 
 template <class A>
-__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
-                                                                    unsigned n_desc, unsigned subs, int pb) {
+__device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typename A::K &k, u64 *lds, const int t) {
     using namespace n14;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
-    const int t = threadIdx.x;
-    const unsigned sub = blockIdx.x;
-    const ModDesc &D = descs[(sub >> pb) % n_desc];
-    const typename A::K k = A::make(D, 14, pb, int(sub & ((1u << pb) - 1)));
-    u64 *g = data + (size_t(sub) << 14);
     u64 x[32];
     typename A::TwRaw ta[8], tb[8];
     const int t1 = t >> 5, t2 = t >> 1;  // block prefixes of passes 1 and 2; pass 3: (s3 << 9) | t
     STAMP(0);
-    if constexpr (A::PREFETCH) tw_load<A, false, P0<0>>(ta, 0, k);
+    if constexpr (ahead<A, P0<0>>()) tw_load<A, false, P0<0>>(ta, 0, k);
     // pass 0: layers 0..3
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = g[((r & 15) << 10) | ((r >> 4) << 9) | t];
@@ -344,21 +338,27 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restri
     STAMP(9);
 }
 
-template <class A>
-__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+// PFX = false: a whole 2^14 ring (pb = 0): the block prefix and the table offset are compile-time zeros, which takes the
+// variable shifts out of every twiddle index.  PFX = true: sub-transform sub & (2^pb - 1) of polynomial sub >> pb.
+template <class A, bool PFX>
+__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                     unsigned n_desc, unsigned subs, int pb) {
-    using namespace n14;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
-    const int t = threadIdx.x;
     const unsigned sub = blockIdx.x;
-    const ModDesc &D = descs[(sub >> pb) % n_desc];
-    const typename A::K k = A::make(D, 14, pb, int(sub & ((1u << pb) - 1)));
-    u64 *g = data + (size_t(sub) << 14);
+    const unsigned poly = PFX ? sub >> pb : sub;
+    const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
+    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
+}
+
+template <class A>
+__device__ __forceinline__ void ntt14_inv_body(u64 *__restrict__ g, const typename A::K &k, u64 *lds, const int t) {
+    using namespace n14;
     u64 x[32];
     typename A::TwRaw ta[8], tb[8];
     const int t1 = t >> 5, t2 = t >> 1;
-    if constexpr (A::PREFETCH) tw_load<A, true, P3<1, 0>>(ta, t, k);
+    if constexpr (ahead<A, P3<1, 0>>()) tw_load<A, true, P3<1, 0>>(ta, t, k);
     // pass 3: layers 13..12
 #pragma unroll
     for (int s3 = 0; s3 < 8; ++s3) {
@@ -387,6 +387,20 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restri
     istep<A, P0<0>, void>(x, tb, ta, 0, 0, k);
 #pragma unroll
     for (int r = 0; r < 32; ++r) g[((r & 15) << 10) | ((r >> 4) << 9) | t] = A::finish_inv(x[r], k);
+}
+
+// PFX = false: a whole 2^14 ring (pb = 0): the block prefix and the table offset are compile-time zeros, which takes the
+// variable shifts out of every twiddle index.  PFX = true: sub-transform sub & (2^pb - 1) of polynomial sub >> pb.
+template <class A, bool PFX>
+__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                    unsigned n_desc, unsigned subs, int pb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const unsigned sub = blockIdx.x;
+    const unsigned poly = PFX ? sub >> pb : sub;
+    const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
+    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    ntt14_inv_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
 }
 
 }  // namespace fhe

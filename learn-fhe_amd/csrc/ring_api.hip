@@ -70,7 +70,8 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // (tools/ntt_lab.hip: 0.446 / 0.448 ms against 0.486 / 0.481 ms for 4096 pseudo-Mersenne transforms)
 template <class A>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
-    auto k = inv ? fhe::ntt14_inv_kernel<A> : fhe::ntt14_fwd_kernel<A>;
+    auto k = pb ? (inv ? fhe::ntt14_inv_kernel<A, true> : fhe::ntt14_fwd_kernel<A, true>)
+                : (inv ? fhe::ntt14_inv_kernel<A, false> : fhe::ntt14_fwd_kernel<A, false>);
     HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fhe::N14_LDS_BYTES));
     hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::N14_THREADS), fhe::N14_LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());

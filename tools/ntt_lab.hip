@@ -20,9 +20,37 @@ struct ArithNone : ArithPM<60> {  // exchanges + HBM traffic only
 struct ArithNoTw : ArithPM<60> {  // butterflies with a computed twiddle: no twiddle loads
     template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) { return TwRaw{k.ninv.wl + (unsigned)idx, k.ninv.wh}; }
 };
-struct ArithPrefetch : ArithPM<60> {  // the same arithmetic with the one-unit-ahead twiddle prefetch
-    static constexpr bool PREFETCH = true;
+struct ArithPrefetch : ArithPM<60> {  // the same arithmetic with every twiddle set fetched one unit ahead
+    static constexpr int PREFETCH = 8;
 };
+struct ArithPrefetch4 : ArithPM<60> {  // only sets of <= 4 twiddles ahead
+    static constexpr int PREFETCH = 4;
+};
+struct ArithPrefetch2 : ArithPM<60> {
+    static constexpr int PREFETCH = 2;
+};
+// experiment: persistent workgroups (2 per CU) looping over polynomials, the second workgroup of a CU starting late
+template <class A>
+__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_persistent(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                        unsigned n_desc, unsigned subs, int delay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const typename A::K k = A::make(descs[0], 14, 0, 0);
+    if (blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+    for (unsigned sub = blockIdx.x; sub < subs; sub += gridDim.x) ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
+}
+// experiment: the ordinary one-polynomial-per-workgroup kernel, second resident generation (blocks 256..511) starts late
+template <class A>
+__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_dephased(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                      unsigned n_desc, unsigned subs, int delay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const typename A::K k = A::make(descs[0], 14, 0, 0);
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+    ntt14_fwd_body<A>(data + (size_t(blockIdx.x) << 14), k, lds, threadIdx.x);
+}
 #ifndef LAB_LOG_N
 #define LAB_LOG_N 14
 #endif
@@ -95,11 +123,14 @@ int main(int argc, char **argv) {
     struct Variant { const char *name; kern_t f, i; };
     struct V14 { const char *name; kern_t f, i; };
     V14 v14[] = {
-        {"ntt14 Shoup (512 thr, 2 WG/CU)", ntt14_fwd_kernel<ArithShoup>, ntt14_inv_kernel<ArithShoup>},
-        {"ntt14 pseudo-Mersenne", ntt14_fwd_kernel<ArithPM<60>>, ntt14_inv_kernel<ArithPM<60>>},
-        {"ntt14 ablation: no butterflies", ntt14_fwd_kernel<ArithNone>, ntt14_inv_kernel<ArithNone>},
-        {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw>, ntt14_inv_kernel<ArithNoTw>},
-        {"ntt14 pseudo-Mersenne, twiddle prefetch", ntt14_fwd_kernel<ArithPrefetch>, ntt14_inv_kernel<ArithPrefetch>},
+        {"ntt14 Shoup (512 thr, 2 WG/CU)", ntt14_fwd_kernel<ArithShoup, false>, ntt14_inv_kernel<ArithShoup, false>},
+        {"ntt14 pseudo-Mersenne", ntt14_fwd_kernel<ArithPM<60>, false>, ntt14_inv_kernel<ArithPM<60>, false>},
+        {"ntt14 pseudo-Mersenne, PFX build", ntt14_fwd_kernel<ArithPM<60>, true>, ntt14_inv_kernel<ArithPM<60>, true>},
+        {"ntt14 ablation: no butterflies", ntt14_fwd_kernel<ArithNone, false>, ntt14_inv_kernel<ArithNone, false>},
+        {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw, false>, ntt14_inv_kernel<ArithNoTw, false>},
+        {"ntt14 pseudo-Mersenne, twiddle prefetch", ntt14_fwd_kernel<ArithPrefetch, false>, ntt14_inv_kernel<ArithPrefetch, false>},
+        {"ntt14 pseudo-Mersenne, prefetch <= 4", ntt14_fwd_kernel<ArithPrefetch4, false>, ntt14_inv_kernel<ArithPrefetch4, false>},
+        {"ntt14 pseudo-Mersenne, prefetch <= 2", ntt14_fwd_kernel<ArithPrefetch2, false>, ntt14_inv_kernel<ArithPrefetch2, false>},
     };
     Variant vars[] = {
         {"generic Shoup, fwd staged / inv direct", ntt_fwd_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, false>, ntt_inv_kernel<ArithShoup, LAB_LOG_N, 4, 1, false, true>},
@@ -159,6 +190,46 @@ int main(int argc, char **argv) {
             }
             printf("%-36s fwd avg %.4f ms %5.0f GB/s | inv avg %.4f ms %5.0f GB/s | fwd mismatches %zu, round-trip mismatches %zu\n", v.name,
                    sf2 / reps, bytes / (sf2 / reps * 1e-3) / 1e9, si2 / reps, bytes / (si2 / reps * 1e-3) / 1e9, badf, badi);
+        }
+        for (int delay : {0, 3, 6, 9}) {  // persistent, dephased (s_sleep 127 = 8128 clocks... x delay)
+            auto pk = ntt14_fwd_persistent<ArithPM<60>>;
+            hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+            for (int grid : {512, 1024}) {
+                float sf2 = 0;
+                for (int r = 0; r < reps + 2; ++r) {
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(pk, dim3(grid), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, delay);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    float f; hipEventElapsedTime(&f, e0, e1);
+                    if (r >= 2) sf2 += f;
+                }
+                printf("persistent fwd grid %4d delay %3d: %.4f ms\n", grid, delay, sf2 / reps);
+            }
+        }
+        for (int delay : {0, 2, 4, 6, 8}) {
+            auto pk = ntt14_fwd_dephased<ArithPM<60>>;
+            hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+            float sf2 = 0;
+            for (int r = 0; r < reps + 2; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(pk, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, delay);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float f; hipEventElapsedTime(&f, e0, e1);
+                if (r >= 2) sf2 += f;
+            }
+            printf("dephased fwd delay %3d: %.4f ms\n", delay, sf2 / reps);
+            sf2 = 0;
+            for (int r = 0; r < reps + 2; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(v14[1].f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float f; hipEventElapsedTime(&f, e0, e1);
+                if (r >= 2) sf2 += f;
+            }
+            printf("   standard fwd kernel, forward-only loop: %.4f ms\n", sf2 / reps);
         }
         {   // occupancy experiment: the same kernel with 100 KiB of dynamic LDS requested -> ONE workgroup per CU
             const size_t big = 100 * 1024;
