@@ -227,13 +227,12 @@ static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bo
     }
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
     if (ma.rc != FHE_OK || mb.rc != FHE_OK) return FHE_ERR_HIP;
-    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
 #define GP_LAUNCH(AR, LN)                                                                                              \
     {                                                                                                                  \
-        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;                                \
+        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;                                \
         rc = set_lds(fhe::gadget_product_kernel<AR, LN>, lds);                                                          \
         if (rc != FHE_OK) return rc;                                                                                    \
-        hipLaunchKernelGGL((fhe::gadget_product_kernel<AR, LN>), dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, ma.d, \
+        hipLaunchKernelGGL((fhe::gadget_product_kernel<AR, LN>), dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, ma.d, \
                            mb.d, (unsigned)batch, key_view(key), (unsigned)index, both ? 1u : 0u, tt, ring_consts(ctx, LN)); \
     }
     if (use_pm54(ctx, key->log_n)) {
@@ -433,13 +432,12 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     BR.lwe_b = mb.d;
     BR.f = mf.d;
     BR.f_stride = f_stride;
-    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
 #define BR_CASE(AR, LN)                                                                                                     \
     case LN: {                                                                                                              \
-        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;                                   \
+        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;                                   \
         rc = set_lds(fhe::blind_rotate_kernel<AR, LN>, lds);                                                                \
         if (rc == FHE_OK)                                                                                                   \
-            hipLaunchKernelGGL((fhe::blind_rotate_kernel<AR, LN>), dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, BR, \
+            hipLaunchKernelGGL((fhe::blind_rotate_kernel<AR, LN>), dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, BR, \
                                moa.d, mob.d, (unsigned)batch, ring_consts(ctx, LN));                                      \
         break;                                                                                                              \
     }

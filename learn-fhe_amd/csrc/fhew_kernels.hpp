@@ -158,16 +158,38 @@ static __global__ void rlwe_sample_extract_kernel(const u64 *__restrict__ ct_a, 
     }
 }
 
-// ---- wave-owned ring element -------------------------------------------------------------------
+// ---- team-owned ring element ---------------------------------------------------------------------
+// One ciphertext belongs to a TEAM of threads that keeps it in registers across a whole chain of gadget products.
+// N <= 512: the team is ONE wave (E = N/64 coefficients per lane, wave-private LDS image, no workgroup barrier anywhere,
+// four teams per block).  N = 1024, 2048: a single wave would need 16 / 32 coefficients per lane for each of the accumulator
+// pair, the evaluation-domain sums and the transform -- 256 VGPRs plus spills, ONE wave per SIMD, nothing to hide an LDS
+// or key-load latency behind (measured at cfg3: the SIMD issues 52 % of the time).  There the team is 2 / 4 waves with 8
+// coefficients per lane, one team per block, exchanges behind a workgroup barrier: half the registers, 3-4 waves per SIMD.
 template <int LOG_N>
 struct WaveRing {
-    static constexpr int LOG_E = LOG_N - 6;
+    static constexpr int LOG_T = LOG_N <= 9 ? 6 : LOG_N - 3;  // log2 threads per ciphertext
+    static constexpr int TEAM = 1 << LOG_T;
+    static constexpr bool WAVE = LOG_T == 6;                   // exchanges need no workgroup barrier
+    static constexpr int TEAMS = WAVE ? 4 : 1;                 // ciphertexts per block
+    static constexpr int THREADS = TEAM * TEAMS;
+    static constexpr int LOG_E = LOG_N - LOG_T;
     static constexpr int E = 1 << LOG_E;
     static constexpr int N = 1 << LOG_N;
-    using C = NttCfg<LOG_N, LOG_E, 1>;  // T = 64: one wave
+    using C = NttCfg<LOG_N, LOG_E, 1>;  // T = TEAM
     static constexpr int R0 = C::R0;
     static constexpr int PN = C::PN;
+    static constexpr size_t LDS_BYTES = size_t(PN) * 8 * TEAMS;
+#ifndef FHE_TEAM_OCC
+#define FHE_TEAM_OCC 2
+#endif
+    // multi-wave teams: waves per SIMD the kernels are compiled for (bounds the VGPRs; HIP's second launch bound).  Measured
+    // at cfg3 / cfg5 (tools/scripts/occ_sweep.sh): 2 -> 47.5k blind rotations/s, 13.1k TFHE gates/s; 3 -> 39.4k / 10.0k;
+    // 4 -> 37.4k / 7.7k: below ~170 VGPRs the accumulator pair, the sums and the digit state spill.
+    static constexpr int MIN_WAVES = WAVE ? 1 : FHE_TEAM_OCC;
     static_assert(LOG_N >= 7 && LOG_N <= 11, "fused FHEW kernels cover N = 128 .. 2048");
+    static_assert(C::T == TEAM, "team size");
+    static __device__ __forceinline__ int lane() { return threadIdx.x & (TEAM - 1); }  // thread within its team
+    static __device__ __forceinline__ int team() { return threadIdx.x >> LOG_T; }      // team within the block
 };
 
 // polynomial index held by register k of `lane` in the coefficient (first-pass) layout
@@ -175,16 +197,16 @@ template <int LOG_N>
 __device__ __forceinline__ int coef_index(int lane, int k) {
     using W = WaveRing<LOG_N>;
     const int gg = k >> W::R0, r = k & ((1 << W::R0) - 1);
-    return pass_index<LOG_N, 0, W::R0>(lane + 64 * gg, r);
+    return pass_index<LOG_N, 0, W::R0>(lane + W::TEAM * gg, r);
 }
 
 // key rows are stored so that the evaluation-layout registers (evaluation lane*E + r in x[r]) load as
 // coalesced 16-byte pairs: word offset of evaluation e = lane*E + r inside a row
 template <int LOG_N>
 __host__ __device__ __forceinline__ int key_perm(int e) {
-    constexpr int E = 1 << (LOG_N - 6);
+    constexpr int E = WaveRing<LOG_N>::E, TEAM = WaveRing<LOG_N>::TEAM;
     const int lane = e / E, r = e % E;
-    return (r >> 1) * 128 + lane * 2 + (r & 1);
+    return (r >> 1) * (2 * TEAM) + lane * 2 + (r & 1);
 }
 
 // what a fused kernel needs besides its arithmetic policy's constants (policy K built from the ModDesc in-kernel)
@@ -195,14 +217,14 @@ struct RingConsts {
 
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
 template <class A, int LOG_N>
-__device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&sa)[1 << (LOG_N - 6)], u64 (&sb)[1 << (LOG_N - 6)],
+__device__ __forceinline__ void mac_row(const u64 (&x)[WaveRing<LOG_N>::E], u64 (&sa)[WaveRing<LOG_N>::E], u64 (&sb)[WaveRing<LOG_N>::E],
                                         const u64 *__restrict__ row, int lane, int term, const RingConsts &K, const typename A::K &k) {
-    constexpr int E = 1 << (LOG_N - 6), N = 1 << LOG_N;
+    constexpr int E = WaveRing<LOG_N>::E, N = 1 << LOG_N, TEAM = WaveRing<LOG_N>::TEAM;
     const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
     const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
 #pragma unroll
     for (int r2 = 0; r2 < E / 2; ++r2) {
-        const ulonglong2 a = ka[r2 * 64 + lane], b = kb[r2 * 64 + lane];
+        const ulonglong2 a = ka[r2 * TEAM + lane], b = kb[r2 * TEAM + lane];
         const u64 x0 = A::mac_in(x[2 * r2], k), x1 = A::mac_in(x[2 * r2 + 1], k);
         sa[2 * r2] = A::mac(sa[2 * r2], x0, a.x, term, k, K.B);
         sa[2 * r2 + 1] = A::mac(sa[2 * r2 + 1], x1, a.y, term, k, K.B);
@@ -219,7 +241,7 @@ __device__ __forceinline__ void mac_row(const u64 (&x)[1 << (LOG_N - 6)], u64 (&
 // Each limb is transformed by the wave-private NTT and multiplied into evaluation-domain sums; two inverse
 // transforms bring the result back.  (ca, cb): coefficient layout, canonical, in and out.
 template <class A, int LOG_N>
-__device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)], u64 (&cb)[1 << (LOG_N - 6)],
+__device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E], u64 (&cb)[WaveRing<LOG_N>::E],
                                                     const u64 *__restrict__ rows, const DecompParams &P, bool both, int lane,
                                                     u64 *lds, const RingConsts &K, const typename A::K &k) {
     using W = WaveRing<LOG_N>;
@@ -237,7 +259,7 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)],
         u64 x[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
-        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, k);
+        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
         mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
@@ -245,7 +267,7 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)],
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, k);
+        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
@@ -259,7 +281,7 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[1 << (LOG_N - 6)],
 
 // util/src/avec.rs:34-50 on a register-resident polynomial: scatter through the wave's LDS image
 template <int LOG_N>
-__device__ __forceinline__ void wave_automorphism(u64 (&c)[1 << (LOG_N - 6)], unsigned t, int lane, u64 *lds, u64 q) {
+__device__ __forceinline__ void wave_automorphism(u64 (&c)[WaveRing<LOG_N>::E], unsigned t, int lane, u64 *lds, u64 q) {
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
 #pragma unroll
@@ -269,24 +291,23 @@ __device__ __forceinline__ void wave_automorphism(u64 (&c)[1 << (LOG_N - 6)], un
         const u64 v = c[k];
         lds[lds_phys(it & (N - 1))] = it < N ? v : (v ? q - v : 0);
     }
-    exchange_sync<true>();
+    exchange_sync<W::WAVE>();
 #pragma unroll
     for (int k = 0; k < E; ++k) c[k] = lds[lds_phys(coef_index<LOG_N>(lane, k))];
-    exchange_sync<true>();
+    exchange_sync<W::WAVE>();
 }
 
 template <int LOG_N>
-__device__ __forceinline__ void wave_load(u64 (&c)[1 << (LOG_N - 6)], const u64 *__restrict__ g, int lane) {
+__device__ __forceinline__ void wave_load(u64 (&c)[WaveRing<LOG_N>::E], const u64 *__restrict__ g, int lane) {
 #pragma unroll
-    for (int k = 0; k < (1 << (LOG_N - 6)); ++k) c[k] = g[coef_index<LOG_N>(lane, k)];
+    for (int k = 0; k < (WaveRing<LOG_N>::E); ++k) c[k] = g[coef_index<LOG_N>(lane, k)];
 }
 template <int LOG_N>
-__device__ __forceinline__ void wave_store(const u64 (&c)[1 << (LOG_N - 6)], u64 *__restrict__ g, int lane) {
+__device__ __forceinline__ void wave_store(const u64 (&c)[WaveRing<LOG_N>::E], u64 *__restrict__ g, int lane) {
 #pragma unroll
-    for (int k = 0; k < (1 << (LOG_N - 6)); ++k) g[coef_index<LOG_N>(lane, k)] = c[k];
+    for (int k = 0; k < (WaveRing<LOG_N>::E); ++k) g[coef_index<LOG_N>(lane, k)] = c[k];
 }
 
-constexpr int FHEW_WAVES_PER_BLOCK = 4;
 
 struct FhewKey {      // device view of a prepared gadget key set
     const u64 *rows;  // [count][rows_per_ct][2][N] evaluation domain, key_perm layout
@@ -298,15 +319,15 @@ struct FhewKey {      // device view of a prepared gadget key set
 //   both = 1: RLWE x RGSW external product; both = 0: RLWE key switch, preceded by X -> X^t2n when t2n != 1
 //   (scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism`)
 template <class A, int LOG_N>
-__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void gadget_product_kernel(
+__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void gadget_product_kernel(
     u64 *__restrict__ ct_a, u64 *__restrict__ ct_b, unsigned batch, FhewKey key, unsigned index, unsigned both, unsigned t2n,
     RingConsts K) {
     using W = WaveRing<LOG_N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
-    if (ct >= batch) return;  // wave-uniform exit; no workgroup barrier is used anywhere
-    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    if (ct >= batch) return;  // team-uniform exit (a multi-wave team is a whole block: barriers stay matched)
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
     const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
     u64 ca[W::E], cb[W::E];
     wave_load<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
@@ -411,15 +432,15 @@ struct BlindRotateParams {
 };
 
 template <class A, int LOG_N>
-__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
+__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
                                                                                   u64 *__restrict__ out_b, unsigned batch, RingConsts K) {
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
     if (ct >= batch) return;
-    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
     const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
     u64 ca[E], cb[E];
     // acc = (0, f.automorphism(-g) * X^(b*g))   (bootstrapping.rs:165-167); both steps are signed index maps
@@ -436,10 +457,10 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void blind_rotate_kernel
             pos = (pos + kmono) & (2 * N - 1);         // * X^k
             lds[lds_phys(pos & (N - 1))] = pos < N ? v : (v ? K.B.q - v : 0);
         }
-        exchange_sync<true>();
+        exchange_sync<W::WAVE>();
 #pragma unroll
         for (int e = 0; e < E; ++e) { cb[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))]; ca[e] = 0; }
-        exchange_sync<true>();
+        exchange_sync<W::WAVE>();
     }
     const unsigned *ops = BR.ops + size_t(ct) * BR.max_ops;
     const unsigned nops = BR.nops[ct];

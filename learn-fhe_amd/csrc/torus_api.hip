@@ -59,12 +59,11 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
     const size_t n = size_t(1) << key->log_n;
     const size_t per = size_t(2 * key->d) * 2 * n;
     const u64 *rows0 = key->d_rows[0] + index * per, *rows1 = key->d_rows[1] + index * per;
-    const unsigned grid = (unsigned)((batch + fhe::FHEW_WAVES_PER_BLOCK - 1) / fhe::FHEW_WAVES_PER_BLOCK);
     TORUS_DISPATCH(key->log_n, {
-        const size_t lds = size_t(fhe::WaveRing<LN>::PN) * 8 * fhe::FHEW_WAVES_PER_BLOCK;
+        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_cmux_kernel<LN>, dim3(grid), dim3(64 * fhe::FHEW_WAVES_PER_BLOCK), lds, st, a, b, (unsigned)batch, rows0,
+        hipLaunchKernelGGL(fhe::torus_cmux_kernel<LN>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
                            rows1, key->P, rot, rot_stride, t->T, scratch);
     });
     HIP_TRY(hipGetLastError());

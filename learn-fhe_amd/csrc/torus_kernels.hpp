@@ -96,8 +96,8 @@ __device__ __forceinline__ u64 crt2_mod64(u64 r0, u64 r1, const TorusConsts &T) 
 template <int LOG_N>
 __device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, const u64 *__restrict__ db, const u64 *__restrict__ rows,
                                                   const TDecomp &P, u64 p, int lane, u64 *lds, const Barrett &B,
-                                                  const typename ArithPM<60>::K &k, u64 (&sa)[1 << (LOG_N - 6)],
-                                                  u64 (&sb)[1 << (LOG_N - 6)]) {
+                                                  const typename ArithPM<60>::K &k, u64 (&sa)[WaveRing<LOG_N>::E],
+                                                  u64 (&sb)[WaveRing<LOG_N>::E]) {
     using A = ArithPM<60>;
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
@@ -119,36 +119,36 @@ __device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, co
             const u64 dg = tdecomp_next(st[e], P);
             x[e] = (long long)dg < 0 ? p - (0 - dg) : dg;  // |digit| <= 2^(log_b-1) < p
         }
-        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, true>(x, lane, nullptr, lds, true, k);
+        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
         mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(sa[e], k); sb[e] = A::mac_finish(sb[e], k); }
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, true>(sa, lane, nullptr, lds, true, k);
+        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
 }
 
-// scheme/tfhe/src/tggsw.rs:100-121 for k = 1, one wave per ciphertext.
+// scheme/tfhe/src/tggsw.rs:100-121 for k = 1, one team (fhew_kernels.hpp: WaveRing) per ciphertext.
 //   rot == nullptr: (a, b) <- external_product(key, (a, b))
 //   rot != nullptr: CMUX step of the blind rotation: (a, b) <- (a, b) + external_product(key, (a, b) X^r - (a, b)),
 //                   r = rot[ct * rot_stride] mod 2N  (acc.rotate(a_i), bootstrapping.rs:94-95)
 // scratch: [batch][4][N] u64 (difference polynomials and the first prime's residues)
 template <int LOG_N>
-__global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void torus_cmux_kernel(
+__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void torus_cmux_kernel(
     u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch, const u64 *__restrict__ rows0, const u64 *__restrict__ rows1,
     TDecomp P, const u64 *__restrict__ rot, size_t rot_stride, TorusConsts T, u64 *__restrict__ scratch) {
     using A = ArithPM<60>;
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned ct = blockIdx.x * FHEW_WAVES_PER_BLOCK + wave;
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
     if (ct >= batch) return;
-    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + wave * W::PN;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
     u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
     u64 *da = scratch + size_t(ct) * 4 * N, *db = da + N, *r0a = db + N, *r0b = r0a + N;
     const bool cmux = rot != nullptr;
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(64 * FHEW_WAVES_PER_BLOCK) void torus_cmux_kernel(
                 const unsigned pos = (unsigned(coef_index<LOG_N>(lane, e)) + r) & (2 * N - 1);
                 lds[lds_phys(pos & (N - 1))] = pos < N ? c[e] : 0 - c[e];
             }
-            exchange_sync<true>();
+            exchange_sync<W::WAVE>();
 #pragma unroll
             for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))] - c[e];
-            exchange_sync<true>();
+            exchange_sync<W::WAVE>();
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) dst[coef_index<LOG_N>(lane, e)] = c[e];

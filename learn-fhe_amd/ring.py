@@ -34,7 +34,7 @@ class NttContext:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_ctx_destroy(h)
 
     @property
@@ -132,7 +132,7 @@ class GadgetKey:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_key_destroy(h)
 
     @property
@@ -228,7 +228,7 @@ class BootstrapKey:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_bootstrap_key_destroy(h)
 
     def bootstrap(self, q_ks, ks_log_b, ks_d, lwe_ksk_a, lwe_ksk_b, f, ct_a, ct_b, addend=0):
@@ -286,7 +286,7 @@ class RnsContext:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_rns_ctx_destroy(h)
 
     @property
@@ -325,7 +325,7 @@ class CkksKey:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_ckks_key_destroy(h)
 
     def key_switch_(self, ct_b, ct_a):
@@ -355,7 +355,7 @@ class TorusContext:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_torus_ctx_destroy(h)
 
     @property
@@ -391,7 +391,7 @@ class TggswKey:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and L is not None and getattr(L, "lib", None):  # (module globals are gone at interpreter shutdown)
             L.lib().fhe_tggsw_key_destroy(h)
 
     def external_product_(self, index, ct_a, ct_b):

@@ -1,0 +1,8 @@
+#!/bin/bash
+# experiment: the fused kernels compiled for 2 / 3 / 4 waves per SIMD (FHE_TEAM_OCC), secondary bench figures of each
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+for occ in 2 3 4; do
+  cp $R/tools/libfhe_occ$occ.so $R/learn-fhe_amd/lib/libfhe_ring.so
+  echo "== occ $occ"
+  python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print(d['fhew']); print(d['tfhe'])"
+done
