@@ -23,6 +23,9 @@ __device__ __forceinline__ const FHE_GLOBAL T *as_global(const T *p) {
     return (const FHE_GLOBAL T *)p;
 }
 
+// non-template kernels defined in headers that several translation units include (each unit uses a subset)
+#define FHE_HEADER_KERNEL static __attribute__((unused)) __global__
+
 template <int I, int END, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < END) {

@@ -37,7 +37,7 @@ __device__ __forceinline__ u64 decomp_next(u64 &c, const DecompParams &P) {
 }
 
 // in: [polys][n]   out: [polys][d][n] (digit-major per polynomial, least significant first)
-static __global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, DecompParams P) {
+FHE_HEADER_KERNEL void decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, DecompParams P) {
     const size_t total = n * polys;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -47,7 +47,7 @@ static __global__ void decompose_kernel(const u64 *__restrict__ in, u64 *__restr
 }
 
 // ---- automorphism X -> X^t (util/src/avec.rs:34-50) and monomial multiply (util/src/ring.rs:299-313) ----
-static __global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned t, u64 q) {
+FHE_HEADER_KERNEL void automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned t, u64 q) {
     const size_t total = size_t(n) * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n;
@@ -59,7 +59,7 @@ static __global__ void automorphism_kernel(const u64 *__restrict__ in, u64 *__re
     }
 }
 
-static __global__ void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned k2n, u64 q) {
+FHE_HEADER_KERNEL void monomial_mul_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t batch, unsigned k2n, u64 q) {
     const size_t total = size_t(n) * batch;
     const unsigned r = k2n & (n - 1);
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ u64 zq_mod_switch(u64 v, u64 q, u64 q_prime, bool odd
     return ((u64)u | 1ull) % q_prime;
 }
 
-static __global__ void lwe_mod_switch_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 q, u64 q_prime, int odd) {
+FHE_HEADER_KERNEL void lwe_mod_switch_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 q, u64 q_prime, int odd) {
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
         out[idx] = zq_mod_switch(in[idx], q, q_prime, odd != 0);
 }
@@ -95,7 +95,7 @@ static __global__ void lwe_mod_switch_kernel(const u64 *__restrict__ in, u64 *__
 // scheme/fhew/src/lwe.rs:151-160 `Lwe::key_switch`: one thread per (ciphertext, output coefficient); column n_out carries b.
 // ksk_a [d * n_in][n_out], ksk_b [d * n_in]; row j * n_in + i = digit j of input coefficient i (`decompose(a).flatten()`).
 // q < 2^32 (the FHEW key-switching moduli are 2^16 .. 2^20), so products fit 64 bits.
-static __global__ void lwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
+FHE_HEADER_KERNEL void lwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
                                              size_t batch, const u64 *__restrict__ ksk_a, const u64 *__restrict__ ksk_b, DecompParams P,
                                              u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
     const size_t total = size_t(n_out + 1) * batch;
@@ -124,7 +124,7 @@ struct LinComb {
     long long coef[4];
     int k;
 };
-static __global__ void lwe_lincomb_kernel(LinComb lc, u64 q, u64 addend, u64 *__restrict__ out, size_t count) {
+FHE_HEADER_KERNEL void lwe_lincomb_kernel(LinComb lc, u64 q, u64 addend, u64 *__restrict__ out, size_t count) {
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x) {
         u64 acc = addend;
         for (int t = 0; t < lc.k; ++t) {
@@ -144,7 +144,7 @@ static __global__ void lwe_lincomb_kernel(LinComb lc, u64 q, u64 addend, u64 *__
 }
 
 // scheme/fhew/src/rlwe.rs:193-202 `Rlwe::sample_extract(ct, i)`; `addend` is added to b (Fhew::op's + Q/8, fhew.rs:39)
-static __global__ void rlwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
+FHE_HEADER_KERNEL void rlwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
                                                   u64 q, u64 addend, u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
     const size_t total = size_t(n) * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
 
 // evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout
 template <int LOG_N>
-static __global__ void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
+FHE_HEADER_KERNEL void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
     constexpr int N = 1 << LOG_N;
     const size_t total = rows * N;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -361,7 +361,7 @@ constexpr unsigned BR_OP_AK = 0x80000000u;
 
 // One thread per ciphertext restates i_minus_i_plus + the walk of blind_rotate_core into an op list.
 // dlog[x] for x in [0, 2N): (l << 1) | sign (sign 1 = "minus" map), 0xffffffff if x is not +-5^l (even x)
-static __global__ void blind_rotate_schedule_kernel(const u64 *__restrict__ lwe_a, unsigned n_lwe, unsigned batch, unsigned n, unsigned w,
+FHE_HEADER_KERNEL void blind_rotate_schedule_kernel(const u64 *__restrict__ lwe_a, unsigned n_lwe, unsigned batch, unsigned n, unsigned w,
                                              const unsigned *__restrict__ dlog, unsigned *__restrict__ ops, unsigned *__restrict__ nops,
                                              unsigned max_ops, unsigned *__restrict__ scratch /* [batch][2 * n_lwe + n + 2] */,
                                              int *__restrict__ err) {

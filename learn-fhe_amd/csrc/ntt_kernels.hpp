@@ -301,7 +301,7 @@ __global__ void ntt_big_inv_pass(u64 *__restrict__ data, const ModDesc *__restri
         const unsigned poly = unsigned(idx >> lc);
         const size_t low = idx & ((size_t(1) << lc) - 1);
         const ModDesc &D = descs[poly % n_desc];
-        const u64 q = D.q, q2 = 2 * q;
+        const u64 q = D.q;
         u64 *g = data + (size_t(poly) << log_n) + low;
         u64 x[1 << PB];
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ void ntt_big_inv_pass(u64 *__restrict__ data, const ModDesc *__restri
 }
 
 // a[i] <- a[i] * b[i] mod q (evaluation-domain product, util/src/ring.rs:266-270)
-static __global__ void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t len, Barrett B) {
+FHE_HEADER_KERNEL void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t len, Barrett B) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < len; i += size_t(gridDim.x) * blockDim.x)
         a[i] = mulmod_barrett(a[i], b[i], B);
 }

@@ -43,7 +43,7 @@ __device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64
 }
 
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
-static __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
+FHE_HEADER_KERNEL void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
                                   BaseConv C) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -66,7 +66,7 @@ struct RescaleConsts {
 
 // util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
-static __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
+FHE_HEADER_KERNEL void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
                                    const u64 *addend, size_t add_bs, size_t n, size_t batch, RescaleConsts R) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -95,7 +95,7 @@ static __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_
 }
 
 // ob = kb (.) e, oa = ka (.) e limb-wise in the evaluation domain; e, ob, oa: [batch][lk][n]; kb, ka: [lk][n]
-static __global__ void rns_pointwise2_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
+FHE_HEADER_KERNEL void rns_pointwise2_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
                                       u64 *__restrict__ ob, u64 *__restrict__ oa, size_t n, int lk, size_t batch,
                                       const Barrett *__restrict__ B) {
     const size_t per = n * size_t(lk), total = per * batch;

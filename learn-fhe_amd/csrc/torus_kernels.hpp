@@ -31,7 +31,7 @@ __device__ __forceinline__ u64 tdecomp_next(u64 &c, const TDecomp &P) {
 }
 
 // in [polys][n] -> out [polys][d][n]
-static __global__ void torus_decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, TDecomp P) {
+FHE_HEADER_KERNEL void torus_decompose_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, TDecomp P) {
     const size_t total = n * polys;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -49,14 +49,14 @@ __device__ __forceinline__ u64 signed_residue(u64 v, u64 p) {
 }
 
 // rows [rows][n] signed torus values -> residues mod the prime of descs[prime]
-static __global__ void torus_residue_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 p) {
+FHE_HEADER_KERNEL void torus_residue_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, u64 p) {
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
         out[idx] = signed_residue(in[idx], p);
 }
 
 // multiplication by X^k on the torus (ring.rs:299-313, negation = wrapping_neg), per-polynomial shift:
 // k = shift[p * stride] taken mod 2n; neg_shift: use -k (acc.rotate(-b), bootstrapping.rs:93)
-static __global__ void torus_monomial_kernel(const u64 *__restrict__ in, size_t in_stride, u64 *__restrict__ out, unsigned n, size_t batch,
+FHE_HEADER_KERNEL void torus_monomial_kernel(const u64 *__restrict__ in, size_t in_stride, u64 *__restrict__ out, unsigned n, size_t batch,
                                       const u64 *__restrict__ shift, size_t stride, int neg_shift) {
     const size_t total = size_t(n) * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
 }
 
 // exact torus product building blocks for fhe_torus_mul: c = a * b with |b| small (two-prime CRT)
-static __global__ void torus_crt_kernel(const u64 *__restrict__ r /* [batch][2][n] */, u64 *__restrict__ out, size_t n, size_t batch, TorusConsts T) {
+FHE_HEADER_KERNEL void torus_crt_kernel(const u64 *__restrict__ r /* [batch][2][n] */, u64 *__restrict__ out, size_t n, size_t batch, TorusConsts T) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -210,7 +210,7 @@ static __global__ void torus_crt_kernel(const u64 *__restrict__ r /* [batch][2][
 }
 
 // a, b [batch][n] signed torus values -> ra, rb [batch][2][n] residues
-static __global__ void torus_residue2_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t batch, u64 p0, u64 p1) {
+FHE_HEADER_KERNEL void torus_residue2_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t batch, u64 p0, u64 p1) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -221,7 +221,7 @@ static __global__ void torus_residue2_kernel(const u64 *__restrict__ in, u64 *__
 }
 
 // ra <- ra (.) rb per prime; [batch][2][n]
-static __global__ void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *__restrict__ rb, size_t n, size_t batch, Barrett B0, Barrett B1) {
+FHE_HEADER_KERNEL void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *__restrict__ rb, size_t n, size_t batch, Barrett B0, Barrett B1) {
     const size_t total = 2 * n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const bool second = (idx / n) & 1;
@@ -230,7 +230,7 @@ static __global__ void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *_
 }
 
 // scheme/tfhe/src/tglwe.rs:115-127 (k = 1): [batch][n] a, b -> TLWE a [batch][n], b [batch]
-static __global__ void tglwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
+FHE_HEADER_KERNEL void tglwe_sample_extract_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n, size_t batch, unsigned i,
                                             u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
     const size_t total = size_t(n) * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -244,7 +244,7 @@ static __global__ void tglwe_sample_extract_kernel(const u64 *__restrict__ ct_a,
 
 // scheme/tfhe/src/tlwe.rs:144-153: one thread per (ciphertext, output coefficient); ksk_a [n_in*d][n_out], ksk_b [n_in*d]
 // (row index j * n_in + i: digit-major, as `decompose(a).flatten()` orders the limbs); output index n_out carries b
-static __global__ void tlwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
+FHE_HEADER_KERNEL void tlwe_key_switch_kernel(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in, unsigned n_out,
                                        size_t batch, const u64 *__restrict__ ksk_a, const u64 *__restrict__ ksk_b, TDecomp P,
                                        u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
     const size_t total = size_t(n_out + 1) * batch;
@@ -266,7 +266,7 @@ static __global__ void tlwe_key_switch_kernel(const u64 *__restrict__ ct_a, cons
 }
 
 // util/src/torus-side rounding_shr used by bootstrapping.rs:99-104 `mod_switch`
-static __global__ void torus_rounding_shr_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, int bits) {
+FHE_HEADER_KERNEL void torus_rounding_shr_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, int bits) {
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
         out[idx] = (in[idx] + ((u64(1) << bits) >> 1)) >> bits;
 }

@@ -74,3 +74,26 @@ def test_status_codes(fhe):
     big = np.zeros(2048, dtype=np.uint64)
     rc = lib.fhe_ntt_fwd(ctx.handle, big.ctypes.data_as(C.c_void_p), 2048, 1, 0, None)
     assert rc == 3  # n > 2^(s-1): no 2n-th root (fft.rs:45)
+
+
+def test_host_mirror_of_the_gate_logic(fhe):
+    """Host-side pieces of `Bootstrapping`/`Fhew` that need no device: automorphism exponents (bootstrapping.rs:86-89), Q/8 and
+    Q/4 (bootstrapping.rs:62-68), the gate look-up polynomial (fhew.rs:31-36) -- against the oracle's restatement."""
+    from oracle import pyref as P
+    for n, w in [(8, 2), (128, 3), (512, 10), (1024, 10), (2048, 10)]:
+        assert fhe.ak_t(n, w) == P.ak_t(n, w)
+    for q in (268369921, 18014398509404161, 1152921504606748673):
+        assert fhe.Fhew._round_div(q, 8) == P.zq_from_f64(q, float(q) / 8.0)
+        assert fhe.Fhew._round_div(q, 4) == P.zq_from_f64(q, float(q) / 4.0)
+
+    class _Key:  # the two attributes Fhew reads from a BootstrapKey
+        class ctx:
+            q = 268369921
+
+        class brk:
+            n = 512
+
+    ev = fhe.Fhew(_Key, 1 << 16, 4, 4, None, None)
+    f = ev.table_poly(fhe.Fhew.TABLES["nand"], np.zeros(1, dtype=np.uint64))
+    q8 = ev.big_q_by_8
+    assert f.shape == (512,) and list(f[:128]) == [q8] * 128 and list(f[384:]) == [268369921 - q8] * 128
