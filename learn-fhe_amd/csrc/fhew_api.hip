@@ -8,6 +8,7 @@
 #include "api_common.hpp"
 #include "ctx.hpp"
 #include "fhew_kernels.hpp"
+#include "lwe_kernels.hpp"
 
 // defined in ring_api.hip
 namespace fhe {
@@ -293,8 +294,16 @@ int fhe_lwe_key_switch(uint64_t q, int log_b, int d, const uint64_t *ksk_a, cons
     Mirror mka(ksk_a, rows * n_out, mem, true, st), mkb(ksk_b, rows, mem, true, st), ma(ct_a, n_in * batch, mem, true, st),
         mb(ct_b, batch, mem, true, st), moa(out_a, n_out * batch, mem, false, st), mob(out_b, batch, mem, false, st);
     if (mka.rc | mkb.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
-    hipLaunchKernelGGL(fhe::lwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
-                       (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    const int tile = fhe::ks_tile(batch, rows);
+    if (tile && batch < (size_t(1) << 31)) {  // tiled kernel (lwe_kernels.hpp); sums wrap and are masked once when q is a power of two
+        const bool pow2 = (q & (q - 1)) == 0;
+        const int bad = pow2 ? fhe::launch_key_switch_tiled(fhe::KsZqPow2{P}, ma.d, mb.d, n_in, n_out, batch, mka.d, mkb.d, moa.d, mob.d, tile, st)
+                             : fhe::launch_key_switch_tiled(fhe::KsZq{P}, ma.d, mb.d, n_in, n_out, batch, mka.d, mkb.d, moa.d, mob.d, tile, st);
+        if (bad) return FHE_ERR_HIP;
+    } else {
+        hipLaunchKernelGGL(fhe::lwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d,
+                           (const u64 *)mb.d, (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    }
     HIP_TRY(hipGetLastError());
     rc = moa.sync_out(st);
     return rc != FHE_OK ? rc : mob.sync_out(st);

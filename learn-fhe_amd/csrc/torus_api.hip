@@ -7,6 +7,7 @@
 #include "api_common.hpp"
 #include "ctx.hpp"
 #include "torus_kernels.hpp"
+#include "lwe_kernels.hpp"
 
 struct fhe_torus_ctx {
     int device = -1;
@@ -318,8 +319,13 @@ int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t 
     Mirror mka(ksk_a, rows * n_out, mem, true, st), mkb(ksk_b, rows, mem, true, st), ma(ct_a, n_in * batch, mem, true, st),
         mb(ct_b, batch, mem, true, st), moa(out_a, n_out * batch, mem, false, st), mob(out_b, batch, mem, false, st);
     if (mka.rc | mkb.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
-    hipLaunchKernelGGL(fhe::tlwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d,
-                       (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    const int tile = P.log_b <= 31 ? fhe::ks_tile(batch, rows) : 0;  // the tiled kernel keeps digits as 32-bit words
+    if (tile && batch < (size_t(1) << 31)) {
+        if (fhe::launch_key_switch_tiled(fhe::KsTorus{P}, ma.d, mb.d, n_in, n_out, batch, mka.d, mkb.d, moa.d, mob.d, tile, st)) return FHE_ERR_HIP;
+    } else {
+        hipLaunchKernelGGL(fhe::tlwe_key_switch_kernel, dim3(grid_for((n_out + 1) * batch)), dim3(256), 0, st, (const u64 *)ma.d,
+                           (const u64 *)mb.d, (unsigned)n_in, (unsigned)n_out, batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    }
     HIP_TRY(hipGetLastError());
     rc = moa.sync_out(st);
     return rc != FHE_OK ? rc : mob.sync_out(st);

@@ -297,6 +297,16 @@ def test_lwe_key_switch_and_sample_extract(fhe, cref, torch_cuda):
             assert np.array_equal(host(oa)[i], ea) and int(host(ob)[i]) == eb, (q, i)
     with pytest.raises(fhe.FheError):
         fhe.lwe_key_switch(1 << 40, 4, 4, ksk_a, ksk_b, ct_a, ct_b, n_in, n_out)  # q >= 2^32 is outside this entry's range
+    # ragged batches that take the 2- and 4-ciphertext tiles of the tiled kernel, more output columns than threads of a block
+    for q, lb, d, n_in, n_out, batch in [(1 << 16, 4, 4, 32, 7, 515), (12289, 3, 4, 16, 150, 2050), (1 << 20, 5, 4, 8, 3, 2049)]:
+        ksk_a, ksk_b = rand_u64(21, q, (d * n_in, n_out)), rand_u64(22, q, d * n_in)
+        ct_a, ct_b = rand_u64(23, q, (batch, n_in)), rand_u64(24, q, batch)
+        oa, ob = fhe.lwe_key_switch(q, lb, d, dev(torch_cuda, ksk_a), dev(torch_cuda, ksk_b), dev(torch_cuda, ct_a), dev(torch_cuda, ct_b),
+                                    n_in, n_out)
+        ha, hb = host(oa), host(ob)
+        for i in list(range(0, batch, 37)) + [batch - 2, batch - 1]:
+            ea, eb = cref.lwe_key_switch(q, lb, d, ksk_a, ksk_b, ct_a[i], int(ct_b[i]))
+            assert np.array_equal(ha[i], ea) and int(hb[i]) == eb, (q, i)
     q, n, batch = 18014398509404161, 256, 4
     a, b = rand_u64(5, q, (batch, n)), rand_u64(6, q, (batch, n))
     a[0, :3] = 0

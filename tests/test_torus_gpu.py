@@ -185,3 +185,21 @@ def test_gate_bootstrap_decode_level_reference_parameters(fhe, torch_cuda):
         for m in range(p):
             mu = ((P.tlwe_phase(z, L(host(ka)[m]), int(host(kb)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
             assert mu % p == f(m) % p, (m, mu)
+
+
+def test_tlwe_key_switch_tiles(fhe, torch_cuda):
+    """scheme/tfhe/src/tlwe.rs:144-153 on ragged batches that take the 2- and 4-ciphertext tiles of the tiled kernel"""
+    from oracle import pyref as P
+    rnd = random.Random(21)
+    for log_b, d, n_in, n_out, batch in [(4, 5, 16, 5, 514), (7, 3, 8, 140, 2051)]:
+        dec = P.TorusDecomposor(log_b, d)
+        ksa = [[rnd.getrandbits(64) for _ in range(n_out)] for _ in range(n_in * d)]
+        ksb = [rnd.getrandbits(64) for _ in range(n_in * d)]
+        a = np.random.Generator(np.random.PCG64(batch)).integers(0, 1 << 63, size=(batch, n_in), dtype=np.uint64) * np.uint64(2)
+        b = np.random.Generator(np.random.PCG64(batch + 1)).integers(0, 1 << 63, size=batch, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        a[0, :4] = [0, (1 << 64) - 1, 1 << 63, (1 << 63) - 1]
+        ka, kb = fhe.tlwe_key_switch(log_b, d, dev(torch_cuda, U(ksa)), dev(torch_cuda, U(ksb)), dev(torch_cuda, a), dev(torch_cuda, b), n_in, n_out)
+        ha, hb = host(ka), host(kb)
+        for i in list(range(0, batch, 101)) + [batch - 2, batch - 1]:
+            ya, yb = P.tlwe_key_switch(dec, ksa, ksb, L(a[i]), int(b[i]))
+            assert L(ha[i]) == ya and int(hb[i]) == yb, (batch, i)
