@@ -412,6 +412,7 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     const int log_n = bk->brk->log_n;
     const size_t n = size_t(1) << log_n, n_lwe = bk->brk->count;
     if (f_stride != 0 && f_stride != n) return FHE_ERR_INVALID;
+    if (n_lwe > 4096) return FHE_ERR_UNSUPPORTED;  // the schedule kernel sorts the LWE coefficients in LDS
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return FHE_ERR_HIP;
@@ -419,17 +420,16 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
     if (ma.rc | mb.rc | mf.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
     const unsigned max_ops = (unsigned)(n_lwe + n + 2);
-    const size_t scratch_words = batch * (2 * n_lwe + n + 2);
-    unsigned *ws = nullptr;  // ops | nops | scratch | err
-    const size_t ws_words = batch * max_ops + batch + scratch_words + 1;
+    unsigned *ws = nullptr;  // ops | nops | err
+    const size_t ws_words = batch * max_ops + batch + 1;
     HIP_TRY(hipMalloc((void **)&ws, ws_words * sizeof(unsigned)));
-    unsigned *d_ops = ws, *d_nops = ws + batch * max_ops, *d_scratch = d_nops + batch;
-    int *d_err = (int *)(d_scratch + scratch_words);
+    unsigned *d_ops = ws, *d_nops = ws + batch * max_ops;
+    int *d_err = (int *)(d_nops + batch);
     int rc = FHE_OK;
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(ws); return code; };
     if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) return fail(FHE_ERR_HIP);
-    hipLaunchKernelGGL(fhe::blind_rotate_schedule_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ma.d, (unsigned)n_lwe,
-                       (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_scratch, d_err);
+    hipLaunchKernelGGL(fhe::blind_rotate_schedule_kernel, dim3((unsigned)batch), dim3(64), 3 * n_lwe * sizeof(unsigned), st, ma.d,
+                       (unsigned)n_lwe, (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_err);
     if (hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
     fhe::BlindRotateParams BR;
     BR.brk = key_view(bk->brk);

@@ -215,6 +215,31 @@ def test_blind_rotate_vs_oracle_small(fhe, cref, torch_cuda):
         bk.blind_rotate(dev(torch_cuda, bad), dev(torch_cuda, lwe_b), dev(torch_cuda, f))
 
 
+@pytest.mark.parametrize("w", [1, 2, 5, 31])
+def test_blind_rotate_schedule_random(fhe, cref, torch_cuda, w):
+    """the device-side LMKCDEY walk (sorted-run restatement) against the oracle's level-by-level loop, many random LWE vectors:
+    dense and sparse buckets, zeros, every window size w up to N/4 - 1"""
+    q, n, lb, d, n_lwe, batch = 18014398509404161, 128, 6, 3, 40, 48
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, 5, 4, w, n_lwe, seed=80 + w)
+    rng = np.random.Generator(np.random.PCG64(100 + w))
+    lwe_a = (rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_a[rng.random(size=lwe_a.shape) < 0.2] = 0          # rotations by zero are skipped
+    lwe_a[1, :] = 1                                          # everything in bucket (plus, 0)
+    lwe_a[2, :] = 2 * n - 1                                  # everything in bucket (minus, 0)
+    lwe_a[3, :] = 0
+    lwe_a[4, :] = 5                                          # (plus, 1): the level next to the end of the walk
+    lwe_a[5, :20] = pow(5, n // 2 - 1, 2 * n)                # (plus, top level)
+    lwe_a[5, 20:] = 2 * n - pow(5, n // 2 - 1, 2 * n)        # (minus, top level)
+    lwe_b = rng.integers(0, 2 * n, size=batch, dtype=np.uint64)
+    f = rand_u64(79, q, n)
+    oa, ob, sched = bk.blind_rotate(dev(torch_cuda, lwe_a), dev(torch_cuda, lwe_b), dev(torch_cuda, f), want_schedule=True)
+    for i in range(batch):
+        assert sched[i] == cref.blind_rotate_schedule(n, w, lwe_a[i]), (w, i)
+    for i in (0, 5):
+        ea, eb = cref.blind_rotate(q, n, w, lb, d, 5, 4, brk, ak, ts, f, lwe_a[i], int(lwe_b[i]))
+        assert np.array_equal(host(oa)[i], ea) and np.array_equal(host(ob)[i], eb), i
+
+
 def test_blind_rotate_cfg3(fhe, cref, torch_cuda):
     """BASELINE config 3: N = 2^10, q = 18014398509404161, base 2^6, d = 9, n = 100, w = 10 -- the full CMUX loop,
     bit-exact against the oracle on 2 ciphertexts (uniform-random keys: validity is irrelevant for parity)."""
