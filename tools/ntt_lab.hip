@@ -38,7 +38,26 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_persistent(u64 *__re
     const typename A::K k = A::make(descs[0], 14, 0, 0);
     if (blockIdx.x >= gridDim.x / 2)
         for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
-    for (unsigned sub = blockIdx.x; sub < subs; sub += gridDim.x) ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
+    for (unsigned sub = blockIdx.x; sub < subs; sub += gridDim.x) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, t);
+    }
+}
+// experiment: PER polynomials per workgroup, back to back (fewer workgroup launches, still dynamically dispatched)
+template <class A, int PER>
+__global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_multi(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                   unsigned n_desc, unsigned subs, int) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const typename A::K k = A::make(descs[0], 14, 0, 0);
+#pragma unroll 1
+    for (int r = 0; r < PER; ++r) {
+        const unsigned sub = blockIdx.x * PER + r;
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));  // opaque per iteration: keeps the twiddle address arithmetic inside the loop body (no LICM -> no spills)
+        if (sub < subs) ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, t);
+    }
 }
 // experiment: the ordinary one-polynomial-per-workgroup kernel, second resident generation (blocks 256..511) starts late
 template <class A>
@@ -207,7 +226,31 @@ int main(int argc, char **argv) {
                 printf("persistent fwd grid %4d delay %3d: %.4f ms\n", grid, delay, sf2 / reps);
             }
         }
-        for (int delay : {0, 2, 4, 6, 8}) {
+        {   // forward-kernel variants, interleaved rounds (fwd variant, then the product inverse), so clocks and thermals are shared
+            typedef void (*kern_t2)(u64 *, const ModDesc *, unsigned, unsigned, int);
+            struct { const char *name; kern_t2 f; int per; float sum; } mv[] = {
+                {"product kernel (ntt14_fwd_kernel<PM60, false>)", ntt14_fwd_kernel<ArithPM<60>, false>, 1, 0},
+                {"1 polynomial per workgroup, opaque thread id", ntt14_fwd_multi<ArithPM<60>, 1>, 1, 0},
+                {"2 polynomials per workgroup", ntt14_fwd_multi<ArithPM<60>, 2>, 2, 0},
+                {"4 polynomials per workgroup", ntt14_fwd_multi<ArithPM<60>, 4>, 4, 0},
+                {"persistent, 512 workgroups", ntt14_fwd_persistent<ArithPM<60>>, 0, 0},
+                {"persistent, 1024 workgroups", ntt14_fwd_persistent<ArithPM<60>>, -1, 0}};
+            for (auto &m : mv) hipFuncSetAttribute((const void *)m.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+            for (int r = 0; r < reps + 2; ++r)
+                for (auto &m : mv) {
+                    const int grid = m.per > 0 ? batch / m.per : (m.per == 0 ? 512 : 1024);
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(m.f, dim3(grid), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                    hipEventRecord(e1);
+                    hipLaunchKernelGGL(v14[1].i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                    hipEventRecord(e2);
+                    hipEventSynchronize(e2);
+                    float f; hipEventElapsedTime(&f, e0, e1);
+                    if (r >= 2) m.sum += f;
+                }
+            for (auto &m : mv) printf("fwd A/B, %-48s %.4f ms\n", m.name, m.sum / reps);
+        }
+        for (int delay : {0, 4}) {
             auto pk = ntt14_fwd_dephased<ArithPM<60>>;
             hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
             float sf2 = 0;
