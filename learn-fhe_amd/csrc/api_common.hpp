@@ -42,6 +42,36 @@ struct DeviceGuard {
     }
 };
 
+// Per-call device workspace, allocated and released IN STREAM ORDER (hipMallocAsync / hipFreeAsync on the device's default
+// pool, whose release threshold is raised once so freed blocks are kept for the next call): an entry point neither pays a
+// device-wide hipMalloc / hipFree nor has to synchronise the stream before it returns to keep its workspace alive.
+struct StreamWs {
+    void *p = nullptr;
+    hipStream_t st;
+    int rc = FHE_OK;
+    StreamWs(size_t bytes, hipStream_t s) : st(s) {
+        static thread_local int pool_ready_for = -1;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && pool_ready_for != dev) {
+            hipMemPool_t pool;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t keep = ~uint64_t(0);
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            pool_ready_for = dev;
+        }
+        const hipError_t e = hipMallocAsync(&p, bytes ? bytes : 8, s);
+        if (e != hipSuccess) { fhe::g_last_hip = (int)e; rc = FHE_ERR_HIP; p = nullptr; }
+    }
+    ~StreamWs() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+    StreamWs(const StreamWs &) = delete;
+    StreamWs &operator=(const StreamWs &) = delete;
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
 // Host-memory convenience path (FHE_MEM_HOST): a device mirror of a host array.  `in`: copy host -> device on
 // construction; sync_out(): copy back.  Device-memory callers (FHE_MEM_DEVICE) get the pointer passed through.
 struct Mirror {

@@ -420,13 +420,14 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
     if (ma.rc | mb.rc | mf.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
     const unsigned max_ops = (unsigned)(n_lwe + n + 2);
-    unsigned *ws = nullptr;  // ops | nops | err
     const size_t ws_words = batch * max_ops + batch + 1;
-    HIP_TRY(hipMalloc((void **)&ws, ws_words * sizeof(unsigned)));
+    StreamWs wsp(ws_words * sizeof(unsigned), st);  // ops | nops | err
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    unsigned *ws = wsp.as<unsigned>();
     unsigned *d_ops = ws, *d_nops = ws + batch * max_ops;
     int *d_err = (int *)(d_nops + batch);
     int rc = FHE_OK;
-    auto fail = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(ws); return code; };
+    auto fail = [&](int code) { return code; };
     if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) return fail(FHE_ERR_HIP);
     hipLaunchKernelGGL(fhe::blind_rotate_schedule_kernel, dim3((unsigned)batch), dim3(64), 3 * n_lwe * sizeof(unsigned), st, ma.d,
                        (unsigned)n_lwe, (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_err);
@@ -473,8 +474,7 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     }
     rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // workspace + h_err must be complete
-    (void)hipFree(ws);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // h_err (and ops_out) must have arrived
     if (rc == FHE_OK && h_err) rc = FHE_ERR_INVALID;  // an LWE coefficient outside the odd residues mod 2N (bootstrapping.rs:221)
     return rc;
 }
@@ -499,9 +499,11 @@ int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b,
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, batch, mem, true, st);
     Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, batch, mem, false, st);
     if (mka.rc | mkb.rc | mf.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
-    uint64_t *ws = nullptr;  // a1 [batch][n] | b1 [batch] | a2 [batch][n_lwe] | b2 [batch] | a3 | b3 | acc_a, acc_b [batch][n]
+    // a1 [batch][n] | b1 [batch] | a2 [batch][n_lwe] | b2 [batch] | a3 | b3 | acc_a, acc_b [batch][n]
     const size_t words = batch * (n + 1 + 2 * (n_lwe + 1) + 2 * n);
-    HIP_TRY(hipMalloc((void **)&ws, words * sizeof(u64)));
+    StreamWs wsp(words * sizeof(u64), st);
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    uint64_t *ws = wsp.as<uint64_t>();
     auto U = [](u64 *p) { return (uint64_t *)p; };
     uint64_t *a1 = ws, *b1 = a1 + batch * n, *a2 = b1 + batch, *b2 = a2 + batch * n_lwe, *a3 = b2 + batch, *b3 = a3 + batch * n_lwe,
         *ra = b3 + batch, *rb = ra + batch * n;
@@ -514,8 +516,6 @@ int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b,
     if (rc == FHE_OK) rc = fhe_rlwe_sample_extract(big_q, ra, rb, n, 0, addend, U(moa.d), U(mob.d), batch, FHE_MEM_DEVICE, stream);
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
-    (void)hipFree(ws);
     return rc;
 }
 

@@ -347,8 +347,9 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
     Mirror ma(a, count, mem, true, st);
     if (ma.rc != FHE_OK) return ma.rc;
     // b is const: transform a scratch copy (the reference allocates one too, fft/zq.rs:21-25)
-    u64 *tb = nullptr;
-    HIP_TRY(hipMalloc((void **)&tb, count * sizeof(u64)));
+    StreamWs ws(count * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *tb = ws.as<u64>();
     hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, ma.d, log_n, batch, st);
@@ -356,9 +357,7 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
     if (rc == FHE_OK) rc = launch_pointwise(ctx, ma.d, tb, count, st);
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_device(ctx, ma.d, log_n, batch, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // tb must outlive the launches
-    (void)hipFree(tb);
-    return rc;
+    return rc;  // tb is released in stream order
 }
 
 }  // extern "C"

@@ -174,6 +174,28 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     return FHE_OK;
 }
 
+namespace {
+// the RNS kernels keep their limb vectors in registers: instantiate for the smallest bound that holds the source base
+#define RNS_BOUND(la, CALL)            \
+    do {                               \
+        if ((la) <= 4) { CALL(4); }    \
+        else if ((la) <= 8) { CALL(8); } \
+        else if ((la) <= 16) { CALL(16); } \
+        else { CALL(32); }             \
+    } while (0)
+void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, hipStream_t st) {
+#define CALL(M) hipLaunchKernelGGL(fhe::rns_extend_kernel<M>, dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C)
+    RNS_BOUND(C.la, CALL);
+#undef CALL
+}
+void launch_rescale(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
+                    const fhe::RescaleConsts &R, hipStream_t st) {
+#define CALL(M) hipLaunchKernelGGL(fhe::rns_rescale_kernel<M>, dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
+    RNS_BOUND(R.K, CALL);
+#undef CALL
+}
+}  // namespace
+
 int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
     if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
     if (r->device < 0) return FHE_ERR_NO_DEVICE;
@@ -183,8 +205,7 @@ int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror mi(in, n * batch * r->L, mem, true, st), mo(out, n * batch * r->K, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    hipLaunchKernelGGL(fhe::rns_extend_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n,
-                       batch, r->q2p);
+    launch_extend(mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, r->q2p, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -199,8 +220,7 @@ int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, s
     const size_t lk = size_t(r->L + r->K);
     Mirror mi(in, n * batch * lk, mem, true, st), mo(out, n * batch * r->L, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, mi.d, lk * n, mo.d, size_t(r->L) * n,
-                       (const u64 *)nullptr, size_t(0), n, batch, r->resc);
+    launch_rescale(mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, r->resc, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -256,16 +276,16 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
     const size_t n = size_t(1) << log_n, L = r->L, lk = size_t(r->L + r->K);
     Mirror mb(ct_b, batch * L * n, mem, true, st), ma(ct_a, batch * L * n, mem, true, st);
     if (mb.rc | ma.rc) return FHE_ERR_HIP;
-    u64 *ws = nullptr;  // ext | pb | pa, each [batch][lk][n]
     const size_t blk = batch * lk * n;
-    HIP_TRY(hipMalloc((void **)&ws, 3 * blk * sizeof(u64)));
+    StreamWs wsp(3 * blk * sizeof(u64), st);  // ext | pb | pa, each [batch][lk][n]
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    u64 *ws = wsp.as<u64>();
     u64 *ext = ws, *pb = ws + blk, *pa = ws + 2 * blk;
     int rc = FHE_OK;
     // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps)
     if (hipMemcpy2DAsync(ext, lk * n * 8, ma.d, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::rns_extend_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, L * n, ext + L * n, lk * n, n,
-                           batch, r->q2p);
+        launch_extend(ma.d, L * n, ext + L * n, lk * n, n, batch, r->q2p, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
@@ -277,16 +297,12 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
     // pb and pa are adjacent: one inverse launch over 2 * batch * lk polynomials
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st, r->all_pm);
     if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)pb, lk * n, mb.d, L * n,
-                           (const u64 *)mb.d, L * n, n, batch, r->resc);
-        hipLaunchKernelGGL(fhe::rns_rescale_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)pa, lk * n, ma.d, L * n,
-                           (const u64 *)nullptr, size_t(0), n, batch, r->resc);
+        launch_rescale(pb, lk * n, mb.d, L * n, mb.d, L * n, n, batch, r->resc, st);
+        launch_rescale(pa, lk * n, ma.d, L * n, nullptr, 0, n, batch, r->resc, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) rc = mb.sync_out(st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // workspace lifetime
-    (void)hipFree(ws);
     return rc;
 }
 

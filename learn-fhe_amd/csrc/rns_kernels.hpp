@@ -21,35 +21,50 @@ struct BaseConv {
     const u64 *ua;          // [lb][la + 1]  (u * A) mod b_j         (rns.rs:315-320 uq_ps)
 };
 
+// The per-coefficient limb vectors live in REGISTERS: every loop over source limbs is unrolled to the compile-time bound MAXA
+// (4 / 8 / 16 / 32, the smallest that holds the base) and predicated on the run-time count -- a run-time trip count would
+// put v[] / vs[] in scratch memory (measured: 57 us -> see DESIGN.md 4.5 for the cfg4 rescale).
+//
 // vs_i = v_i * ahat_inv_i mod a_i; u = round(sum_i frac_i * vs_i) with the reference's sequential f64 sum
-__device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 *v, u64 *vs) {
+template <int MAXA>
+__device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&v)[MAXA], u64 (&vs)[MAXA]) {
     double acc = 0.0;
-    for (int i = 0; i < C.la; ++i) {
-        const u64 a = C.a_mod[i];
-        vs[i] = csub(mul_shoup_lazy(v[i], C.ahat_inv[i], C.ahat_inv_s[i], a), a);
-        acc = __dadd_rn(acc, __dmul_rn(C.frac[i], (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        if (i < C.la) {
+            const u64 a = C.a_mod[i];
+            vs[i] = csub(mul_shoup_lazy(v[i], C.ahat_inv[i], C.ahat_inv_s[i], a), a);
+            acc = __dadd_rn(acc, __dmul_rn(C.frac[i], (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
+        } else {
+            vs[i] = 0;
+        }
     }
     return (int)round(acc);  // f64::round: half away from zero
 }
 
 // sum_i c_ji * vs_i - ua_j[u]  (mod b_j), canonical
-__device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 *vs, int u) {
+template <int MAXA>
+__device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 (&vs)[MAXA], int u) {
     const u64 b = C.b_mod[j], b2 = 2 * b;
     u64 dot = 0;
-    for (int i = 0; i < C.la; ++i) dot = csub(dot + mul_shoup_lazy(vs[i], C.c[j * C.la + i], C.c_s[j * C.la + i], b), b2);
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i)
+        if (i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], C.c[j * C.la + i], C.c_s[j * C.la + i], b), b2);
     dot = csub(dot, b);
     const u64 sub = C.ua[j * (C.la + 1) + u];
     return dot >= sub ? dot - sub : dot + b - sub;
 }
 
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
-FHE_HEADER_KERNEL void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
+template <int MAXA>
+__global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
                                   BaseConv C) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
-        u64 v[RNS_MAX_LIMBS], vs[RNS_MAX_LIMBS];
-        for (int l = 0; l < C.la; ++l) v[l] = in[p * in_bs + size_t(l) * n + i];
+        u64 v[MAXA], vs[MAXA];
+#pragma unroll
+        for (int l = 0; l < MAXA; ++l) v[l] = l < C.la ? in[p * in_bs + size_t(l) * n + i] : 0;
         const int u = base_conv_prepare(C, v, vs);
         for (int j = 0; j < C.lb; ++j) out[p * out_bs + size_t(j) * n + i] = base_conv_out(C, j, vs, u);
     }
@@ -66,13 +81,15 @@ struct RescaleConsts {
 
 // util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
-FHE_HEADER_KERNEL void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
+template <int MAXA>
+__global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
                                    const u64 *addend, size_t add_bs, size_t n, size_t batch, RescaleConsts R) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
-        u64 vp[RNS_MAX_LIMBS], vs[RNS_MAX_LIMBS];
-        for (int j = 0; j < R.K; ++j) vp[j] = csub(in[p * in_bs + size_t(R.L + j) * n + i] + R.half_p[j], R.p_mod[j]);
+        u64 vp[MAXA], vs[MAXA];
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) vp[j] = j < R.K ? csub(in[p * in_bs + size_t(R.L + j) * n + i] + R.half_p[j], R.p_mod[j]) : 0;
         int u = 0;
         if (R.K > 1) u = base_conv_prepare(R.p2q, vp, vs);
         for (int l = 0; l < R.L; ++l) {

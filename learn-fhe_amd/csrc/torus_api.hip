@@ -142,8 +142,9 @@ int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int lo
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror ma(a, n * batch, mem, true, st), mb(b, n * batch, mem, true, st);
     if (ma.rc | mb.rc) return FHE_ERR_HIP;
-    u64 *ws = nullptr;
-    HIP_TRY(hipMalloc((void **)&ws, 4 * n * batch * sizeof(u64)));
+    StreamWs wsp(4 * n * batch * sizeof(u64), st);
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    u64 *ws = wsp.as<u64>();
     u64 *ra = ws, *rb = ws + 2 * n * batch;
     hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, ra, n, batch, t->T.p0, t->T.p1);
     hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)mb.d, rb, n, batch, t->T.p0, t->T.p1);
@@ -160,8 +161,6 @@ int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int lo
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) rc = ma.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
-    (void)hipFree(ws);
     return rc;
 }
 
@@ -234,13 +233,11 @@ int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key,
     const size_t n = size_t(1) << key->log_n;
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
     if (ma.rc | mb.rc) return FHE_ERR_HIP;
-    u64 *scratch = nullptr;
-    HIP_TRY(hipMalloc((void **)&scratch, 4 * n * batch * sizeof(u64)));
-    int rc = launch_cmux(t, key, index, ma.d, mb.d, batch, nullptr, 0, scratch, st);
+    StreamWs ws(4 * n * batch * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    int rc = launch_cmux(t, key, index, ma.d, mb.d, batch, nullptr, 0, ws.as<u64>(), st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
-    (void)hipFree(scratch);
     return rc;
 }
 
@@ -271,8 +268,9 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     Mirror ma(a_tilde, n_lwe * batch, mem, true, st), mb(b_tilde, batch, mem, true, st), mv(v, n, mem, true, st);
     Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
     if (ma.rc | mb.rc | mv.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
-    u64 *scratch = nullptr;
-    HIP_TRY(hipMalloc((void **)&scratch, 4 * n * batch * sizeof(u64)));
+    StreamWs ws(4 * n * batch * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *scratch = ws.as<u64>();
     // acc = (0, v).rotate(-b)   (bootstrapping.rs:91-93)
     int rc = hipMemsetAsync(moa.d, 0, n * batch * sizeof(u64), st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (rc == FHE_OK) {
@@ -284,8 +282,6 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     for (size_t i = 0; i < n_lwe && rc == FHE_OK; ++i) rc = launch_cmux(t, brk, i, moa.d, mob.d, batch, ma.d + i, n_lwe, scratch, st);
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
-    (void)hipFree(scratch);
     return rc;
 }
 
