@@ -71,6 +71,15 @@ int fhe_ntt_inv(const fhe_ctx *ctx, uint64_t *a, size_t n, size_t batch, fhe_mem
  * a[k] <- a[k] * b[k] in Z_q[X]/(X^n+1), coefficient domain in and out. */
 int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
                 void *stream);
+/* util/src/ring.rs:328-358 `Rq` + / - / unary - and 359-366 scalar `*= Zq` (zq.rs:156-196), element-wise over `len`
+ * values of any modulus q < 2^62 (either basis: the operations are the same on coefficients and on evaluations);
+ * `out` may alias an input.  fhe_rq_from_i64: util/src/zq.rs:63-69 `Zq::from_i64` (rem_euclid), the conversion
+ * `Rq *= &AVec<i64>` (ring.rs:272-282) applies to its right-hand side before the product. */
+int fhe_rq_add(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, fhe_mem mem, void *stream);
+int fhe_rq_sub(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, fhe_mem mem, void *stream);
+int fhe_rq_neg(uint64_t q, const uint64_t *a, uint64_t *out, size_t len, fhe_mem mem, void *stream);
+int fhe_rq_scalar_mul(uint64_t q, const uint64_t *a, uint64_t scalar, uint64_t *out, size_t len, fhe_mem mem, void *stream);
+int fhe_rq_from_i64(uint64_t q, const int64_t *in, uint64_t *out, size_t len, fhe_mem mem, void *stream);
 /* util/src/ring.rs:266-270 evaluation-domain `MulAssign`: a[i] <- a[i] * b[i] mod q, len elements. */
 int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t len, fhe_mem mem, void *stream);
 
@@ -156,6 +165,14 @@ typedef struct fhe_ckks_key fhe_ckks_key; /* a key-switching key over qs ++ ps, 
  * prime.  All L+K primes must be distinct (rns.rs:25, 84 asserts).  L, K <= 32. */
 int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int device, fhe_rns_ctx **out);
 void fhe_rns_ctx_destroy(fhe_rns_ctx *rns);
+/* Evaluation-domain residency for `RnsRq`: util/src/ring/rns.rs:40-49 `to_evaluation` /
+ * `to_coefficient` limb by limb in ONE launch, and rns.rs:148-158 the evaluation-basis product.  `extended` = 0:
+ * polynomials over qs, [batch][L][n]; != 0: over qs ++ ps, [batch][L+K][n].  A caller keeps operands in the evaluation
+ * basis on the device across mul -> relinearize -> rescale instead of transforming per operation. */
+int fhe_rns_ntt_fwd(const fhe_rns_ctx *rns, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream);
+int fhe_rns_ntt_inv(const fhe_rns_ctx *rns, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream);
+int fhe_rns_pointwise_mul(const fhe_rns_ctx *rns, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
+                          void *stream);
 /* util/src/ring/rns.rs:83-91 `RnsRq::extend_bases(ps)`: in [batch][L][n] over qs -> out [batch][K][n], the new
  * p-limbs (fast base conversion with the reference's f64 rounding correction, rns.rs:331-345). */
 int fhe_rns_extend_bases(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,

@@ -94,6 +94,14 @@ def lib():
         L.fhe_ckks_key_destroy.restype = None
         L.fhe_ckks_key_switch.argtypes = [vp, vp, vp, vp, sz, ci, vp]
         L.fhe_lwe_mod_switch.argtypes = [C.c_uint64, C.c_uint64, vp, vp, sz, ci, ci, vp]
+        L.fhe_rq_add.argtypes = [C.c_uint64, vp, vp, vp, sz, ci, vp]
+        L.fhe_rq_sub.argtypes = [C.c_uint64, vp, vp, vp, sz, ci, vp]
+        L.fhe_rq_neg.argtypes = [C.c_uint64, vp, vp, sz, ci, vp]
+        L.fhe_rq_scalar_mul.argtypes = [C.c_uint64, vp, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_rq_from_i64.argtypes = [C.c_uint64, vp, vp, sz, ci, vp]
+        L.fhe_rns_ntt_fwd.argtypes = [vp, ci, vp, sz, sz, ci, vp]
+        L.fhe_rns_ntt_inv.argtypes = [vp, ci, vp, sz, sz, ci, vp]
+        L.fhe_rns_pointwise_mul.argtypes = [vp, ci, vp, vp, sz, sz, ci, vp]
         L.fhe_lwe_lincomb.argtypes = [C.c_uint64, ci, vp, vp, C.c_uint64, vp, sz, ci, vp]
         L.fhe_lwe_key_switch.argtypes = [C.c_uint64, ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_rlwe_sample_extract.argtypes = [C.c_uint64, vp, vp, sz, sz, C.c_uint64, vp, vp, sz, ci, vp]

@@ -55,6 +55,17 @@ struct Barrett {
     int sh2;  // n + 1
 };
 
+// host: HAC 14.42 constants for a modulus of 2 .. 62 bits
+inline Barrett make_barrett(u64 q) {
+    const int nbits = 64 - __builtin_clzll(q);
+    Barrett B;
+    B.q = q;
+    B.mu = (u64)((((unsigned __int128)1) << (2 * nbits)) / q);
+    B.sh1 = nbits - 1;
+    B.sh2 = nbits + 1;
+    return B;
+}
+
 // a, b in [0, q)  ->  a*b mod q in [0, q)
 __device__ __forceinline__ u64 mulmod_barrett(u64 a, u64 b, const Barrett &B) {
     u64 lo = a * b, hi = __umul64hi(a, b);

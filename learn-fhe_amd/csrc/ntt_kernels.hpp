@@ -319,4 +319,27 @@ FHE_HEADER_KERNEL void pointwise_mul_kernel(u64 *__restrict__ a, const u64 *__re
         a[i] = mulmod_barrett(a[i], b[i], B);
 }
 
+// util/src/ring.rs:328-366 (`Rq` +, -, unary -, scalar `*= Zq`) and 272-282 (`AVec<i64>` -> Zq, zq.rs:63-69 `from_i64`):
+// element-wise over any modulus q < 2^62; op 0: a + b, 1: a - b, 2: -a, 3: a * scalar, 4: from_i64(a)
+FHE_HEADER_KERNEL void rq_elementwise_kernel(const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out, size_t count, int op,
+                                             u64 scalar, Barrett B) {
+    const u64 q = B.q;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x) {
+        const u64 x = a[idx];
+        u64 r;
+        switch (op) {
+            case 0: r = csub(x + b[idx], q); break;
+            case 1: { const u64 y = b[idx]; r = x >= y ? x - y : x + q - y; break; }
+            case 2: r = x ? q - x : 0; break;
+            case 3: r = mulmod_barrett(x, scalar, B); break;
+            default: {  // i64 -> [0, q): rem_euclid
+                const long long v = (long long)x;
+                const u64 m = (v < 0 ? 0ull - (u64)v : (u64)v) % q;
+                r = (v < 0 && m) ? q - m : m;
+            }
+        }
+        out[idx] = r;
+    }
+}
+
 }  // namespace fhe

@@ -176,10 +176,7 @@ int ctx_build_host(uint64_t q, fhe_ctx *c) {
         const uint64_t cc = (uint64_t(1) << nbits) - q;
         if (cc <= (uint64_t(1) << (nbits - 33))) { c->pm_b = nbits; c->pm_c = (unsigned)cc; }
     }
-    c->barrett.q = q;
-    c->barrett.mu = (u64)((((u128)1) << (2 * nbits)) / q);
-    c->barrett.sh1 = nbits - 1;
-    c->barrett.sh2 = nbits + 1;
+    c->barrett = fhe::make_barrett(q);
     return FHE_OK;
 }
 
@@ -329,6 +326,36 @@ int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t
     int rc = launch_pointwise(ctx, ma.d, mb.d, len, st);
     if (rc != FHE_OK) return rc;
     return ma.sync_out(st);
+}
+
+namespace {
+int rq_elementwise(uint64_t q, const void *a, const void *b, uint64_t *out, size_t len, int op, uint64_t scalar, fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || ((!a || !out || (op < 2 && !b)) && len) || (op == 3 && scalar >= q)) return FHE_ERR_INVALID;
+    if (len == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror ma(a, len, mem, true, st), mb(op < 2 ? b : nullptr, op < 2 ? len : 0, mem, true, st), mo(out, len, mem, false, st);
+    if (ma.rc | mb.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rq_elementwise_kernel, dim3(pass_grid(len)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)mb.d, mo.d, len, op,
+                       (u64)scalar, fhe::make_barrett(q));
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+}  // namespace
+
+int fhe_rq_add(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, fhe_mem mem, void *stream) {
+    return rq_elementwise(q, a, b, out, len, 0, 0, mem, stream);
+}
+int fhe_rq_sub(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, fhe_mem mem, void *stream) {
+    return rq_elementwise(q, a, b, out, len, 1, 0, mem, stream);
+}
+int fhe_rq_neg(uint64_t q, const uint64_t *a, uint64_t *out, size_t len, fhe_mem mem, void *stream) {
+    return rq_elementwise(q, a, nullptr, out, len, 2, 0, mem, stream);
+}
+int fhe_rq_scalar_mul(uint64_t q, const uint64_t *a, uint64_t scalar, uint64_t *out, size_t len, fhe_mem mem, void *stream) {
+    return rq_elementwise(q, a, nullptr, out, len, 3, scalar, mem, stream);
+}
+int fhe_rq_from_i64(uint64_t q, const int64_t *in, uint64_t *out, size_t len, fhe_mem mem, void *stream) {
+    return rq_elementwise(q, in, nullptr, out, len, 4, 0, mem, stream);
 }
 
 int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,

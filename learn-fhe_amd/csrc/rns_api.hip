@@ -225,6 +225,51 @@ int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, s
     return mo.sync_out(st);
 }
 
+namespace {
+// `extended` = 0: polynomials over qs ([batch][L][n]); != 0: over qs ++ ps ([batch][L+K][n])
+int rns_transform(const fhe_rns_ctx *r, int extended, bool inv, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || (!a && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (!is_pow2(n)) return FHE_ERR_INVALID;
+    if (ilog2(n) > r->max_log_n) return FHE_ERR_NO_ROOT;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t limbs = size_t(extended ? r->L + r->K : r->L);
+    Mirror ma(a, n * batch * limbs, mem, true, st);
+    if (ma.rc != FHE_OK) return ma.rc;
+    int rc = FHE_OK;
+    if (n > 1)
+        rc = inv ? fhe::ntt_inv_multi(r->d_descs, (unsigned)limbs, ma.d, ilog2(n), batch * limbs, st, r->all_pm)
+                 : fhe::ntt_fwd_multi(r->d_descs, (unsigned)limbs, ma.d, ilog2(n), batch * limbs, st, r->all_pm);
+    return rc != FHE_OK ? rc : ma.sync_out(st);
+}
+}  // namespace
+
+int fhe_rns_ntt_fwd(const fhe_rns_ctx *r, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return rns_transform(r, extended, false, a, n, batch, mem, stream);
+}
+int fhe_rns_ntt_inv(const fhe_rns_ctx *r, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return rns_transform(r, extended, true, a, n, batch, mem, stream);
+}
+int fhe_rns_pointwise_mul(const fhe_rns_ctx *r, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem,
+                          void *stream) {
+    if (!r || ((!a || !b) && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t limbs = size_t(extended ? r->L + r->K : r->L), count = n * batch * limbs;
+    Mirror ma(a, count, mem, true, st), mb(b, count, mem, true, st);
+    if (ma.rc | mb.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rns_pointwise_kernel, dim3(grid_for(count)), dim3(256), 0, st, ma.d, (const u64 *)mb.d, n, (int)limbs, batch,
+                       (const fhe::Barrett *)r->d_barrett);
+    HIP_TRY(hipGetLastError());
+    return ma.sync_out(st);
+}
+
 void fhe_ckks_key_destroy(fhe_ckks_key *k) {
     if (!k) return;
     if (k->rns && k->rns->device >= 0) {

@@ -125,4 +125,12 @@ FHE_HEADER_KERNEL void rns_pointwise2_kernel(const u64 *__restrict__ e, const u6
     }
 }
 
+// util/src/ring/rns.rs:148-158 `RnsRq *= &RnsRq` (evaluation basis): a[b][l][i] <- a[b][l][i] * b[b][l][i] mod m_l, limbs-major
+FHE_HEADER_KERNEL void rns_pointwise_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t n, int limbs, size_t batch,
+                                            const Barrett *__restrict__ B) {
+    const size_t per = n * size_t(limbs), total = per * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x)
+        a[idx] = mulmod_barrett(a[idx], b[idx], B[(idx % per) / n]);
+}
+
 }  // namespace fhe

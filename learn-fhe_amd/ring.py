@@ -159,6 +159,51 @@ class GadgetKey:
                 "fhe_rlwe_automorphism")
 
 
+def _rq_binary(name, q, a, b):
+    pa, cnt, mem, st = _buf(a)
+    pb, _, _, _ = _buf(b)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(getattr(L.lib(), name)(q, pa, pb, po, cnt, mem, st), name)
+    return out
+
+
+def rq_add(q, a, b):
+    """util/src/ring.rs:343-350 `Rq + Rq` (either basis), any q < 2^62."""
+    return _rq_binary("fhe_rq_add", q, a, b)
+
+
+def rq_sub(q, a, b):
+    """util/src/ring.rs:351-358."""
+    return _rq_binary("fhe_rq_sub", q, a, b)
+
+
+def rq_neg(q, a):
+    pa, cnt, mem, st = _buf(a)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_rq_neg(q, pa, po, cnt, mem, st), "fhe_rq_neg")
+    return out
+
+
+def rq_scalar_mul(q, a, scalar):
+    """util/src/ring.rs:359-366 `Rq *= Zq`."""
+    pa, cnt, mem, st = _buf(a)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_rq_scalar_mul(q, pa, scalar, po, cnt, mem, st), "fhe_rq_scalar_mul")
+    return out
+
+
+def rq_from_i64(q, a):
+    """util/src/zq.rs:63-69 over an array of i64 (torch int64 tensor, or numpy int64 viewed as uint64)."""
+    pa, cnt, mem, st = _buf(a)
+    out = _like(a, tuple(a.shape))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_rq_from_i64(q, pa, po, cnt, mem, st), "fhe_rq_from_i64")
+    return out
+
+
 def lwe_mod_switch(q, q_prime, v, odd=False):
     """util/src/zq.rs:128-140 (scheme/fhew/src/lwe.rs:90-99)."""
     p, cnt, mem, st = _buf(v)
@@ -292,6 +337,22 @@ class RnsContext:
     @property
     def handle(self):
         return self._h
+
+    def ntt_(self, a, n, extended=False, inverse=False):
+        """rns.rs:40-49 limb by limb, in place on [batch][L (+K)][n]."""
+        p, cnt, mem, st = _buf(a)
+        limbs = self.L + self.K if extended else self.L
+        f = L.lib().fhe_rns_ntt_inv if inverse else L.lib().fhe_rns_ntt_fwd
+        L.check(f(self._h, int(extended), p, n, cnt // (limbs * n), mem, st), "fhe_rns_ntt")
+        return a
+
+    def pointwise_mul_(self, a, b, n, extended=False):
+        """rns.rs:148-158 (evaluation basis), in place on a."""
+        pa, cnt, mem, st = _buf(a)
+        pb, _, _, _ = _buf(b)
+        limbs = self.L + self.K if extended else self.L
+        L.check(L.lib().fhe_rns_pointwise_mul(self._h, int(extended), pa, pb, n, cnt // (limbs * n), mem, st), "fhe_rns_pointwise_mul")
+        return a
 
     def extend_bases(self, limbs, n):
         """rns.rs:83-91: [batch][L][n] -> the K new limbs [batch][K][n]."""

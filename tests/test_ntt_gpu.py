@@ -173,3 +173,29 @@ def test_error_behaviour_on_device(fhe, torch_cuda):
     assert e.value.code == 1
     empty = torch_cuda.zeros(0, dtype=torch_cuda.int64, device="cuda")
     ctx.ntt_(empty, 8)  # empty batch is a no-op
+
+
+def test_rq_elementwise_ops(fhe, torch_cuda):
+    """util/src/ring.rs:328-366 (+, -, unary -, scalar *) and zq.rs:63-69 `from_i64`, any modulus < 2^62 (prime or not)"""
+    for q in (1152921504606748673, 1 << 16, 12289, (1 << 62) - 57, 3):
+        a, b = rand_u64(1, q, 5000), rand_u64(2, q, 5000)
+        a[:4] = [0, q - 1, q - 1, 0]
+        b[:4] = [0, q - 1, 1 % q, q - 1]
+        ia, ib = [int(x) for x in a], [int(x) for x in b]
+        da, db = to_dev(torch_cuda, a), to_dev(torch_cuda, b)
+        assert to_host(fhe.rq_add(q, da, db)).tolist() == [(x + y) % q for x, y in zip(ia, ib)]
+        assert to_host(fhe.rq_sub(q, da, db)).tolist() == [(x - y) % q for x, y in zip(ia, ib)]
+        assert to_host(fhe.rq_neg(q, da)).tolist() == [(-x) % q for x in ia]
+        s = (q - 1) if q > 3 else 2
+        assert to_host(fhe.rq_scalar_mul(q, da, s)).tolist() == [x * s % q for x in ia]
+        v = np.random.Generator(np.random.PCG64(3)).integers(-(1 << 62), 1 << 62, size=3000, dtype=np.int64)
+        v[:5] = [0, -1, 1, -(1 << 63), (1 << 63) - 1]
+        out = fhe.rq_from_i64(q, torch_cuda.from_numpy(v).cuda())
+        assert to_host(out).tolist() == [int(x) % q for x in v]
+    # host-memory entry and the range checks of the boundary
+    h = fhe.rq_add(12289, rand_u64(4, 12289, 10), rand_u64(5, 12289, 10))
+    assert h.tolist() == [(int(x) + int(y)) % 12289 for x, y in zip(rand_u64(4, 12289, 10), rand_u64(5, 12289, 10))]
+    with pytest.raises(fhe.FheError):
+        fhe.rq_scalar_mul(12289, rand_u64(4, 12289, 10), 12289)  # scalar not reduced
+    with pytest.raises(fhe.FheError):
+        fhe.rq_add(1 << 62, rand_u64(4, 7, 10), rand_u64(5, 7, 10))  # modulus out of range

@@ -134,3 +134,30 @@ def test_rns_errors(fhe):
     assert lib.fhe_rns_ctx_create(qs, 2, ps, 1, 0, C.byref(h)) == 1  # duplicate modulus (rns.rs:25 all_unique)
     qs = (C.c_uint64 * 2)(1073707009, 15)
     assert lib.fhe_rns_ctx_create(qs, 2, ps, 1, 0, C.byref(h)) == 2  # not prime
+
+
+@pytest.mark.parametrize("log_n,bits,big_l,big_k", [(10, 55, 3, 2), (14, 60, 2, 2), (15, 60, 3, 1)])
+def test_rns_evaluation_residency(fhe, cref, torch_cuda, log_n, bits, big_l, big_k):
+    """util/src/ring/rns.rs:40-49, 148-158: limb-wise transforms in one launch and the evaluation-basis product, over qs and
+    over qs ++ ps, against the single-modulus oracle limb by limb; the product of two RnsRq via the evaluation basis equals
+    the limb-wise negacyclic ring product"""
+    n, batch = 1 << log_n, 2
+    primes = cref.two_adic_primes(bits, log_n + 1, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    for extended, mods in ((False, qs), (True, qs + ps)):
+        a, b = rand_limbs(1, mods, n, batch), rand_limbs(2, mods, n, batch)
+        da, db = dev(torch_cuda, a), dev(torch_cuda, b)
+        rns.ntt_(da, n, extended=extended)
+        ev = host(da)
+        for i in range(batch):
+            for l, m in enumerate(mods):
+                assert np.array_equal(ev[i, l], cref.ntt_fwd(m, a[i, l], n)), (extended, i, l)
+        rns.ntt_(db, n, extended=extended)
+        rns.pointwise_mul_(da, db, n, extended=extended)
+        rns.ntt_(da, n, extended=extended, inverse=True)
+        prod = host(da)
+        for l, m in enumerate(mods):
+            assert np.array_equal(prod[1, l], cref.ntt_mul(m, a[1, l], b[1, l], n)), (extended, l)
+    with pytest.raises(fhe.FheError):
+        rns.ntt_(dev(torch_cuda, rand_limbs(3, qs, 1 << 18, 1)), 1 << 18)  # no 2^19-th root of unity in these primes
