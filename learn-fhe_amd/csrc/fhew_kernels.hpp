@@ -179,6 +179,8 @@ struct WaveRing {
     static constexpr int R0 = C::R0;
     static constexpr int PN = C::PN;
     static constexpr size_t LDS_BYTES = size_t(PN) * 8 * TEAMS;
+    static constexpr int TORUS_LDS_WORDS = PN + 2 * N;  // torus kernels: exchange image + parking area for one residue pair
+    static constexpr size_t TORUS_LDS_BYTES = size_t(TORUS_LDS_WORDS) * 8 * TEAMS;
 #ifndef FHE_TEAM_OCC
 #define FHE_TEAM_OCC 2
 #endif

@@ -56,16 +56,16 @@ inline unsigned grid_for(size_t total) {
     }
 
 int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, u64 *a, u64 *b, size_t batch, const u64 *rot,
-                size_t rot_stride, u64 *scratch, hipStream_t st) {
+                size_t rot_stride, hipStream_t st) {
     const size_t n = size_t(1) << key->log_n;
     const size_t per = size_t(2 * key->d) * 2 * n;
     const u64 *rows0 = key->d_rows[0] + index * per, *rows1 = key->d_rows[1] + index * per;
     TORUS_DISPATCH(key->log_n, {
-        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;
+        const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(fhe::torus_cmux_kernel<LN>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
-                           rows1, key->P, rot, rot_stride, t->T, scratch);
+                           rows1, key->P, rot, rot_stride, t->T);
     });
     HIP_TRY(hipGetLastError());
     return FHE_OK;
@@ -233,9 +233,7 @@ int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key,
     const size_t n = size_t(1) << key->log_n;
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
     if (ma.rc | mb.rc) return FHE_ERR_HIP;
-    StreamWs ws(4 * n * batch * sizeof(u64), st);
-    if (ws.rc != FHE_OK) return ws.rc;
-    int rc = launch_cmux(t, key, index, ma.d, mb.d, batch, nullptr, 0, ws.as<u64>(), st);
+    int rc = launch_cmux(t, key, index, ma.d, mb.d, batch, nullptr, 0, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
@@ -268,18 +266,19 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     Mirror ma(a_tilde, n_lwe * batch, mem, true, st), mb(b_tilde, batch, mem, true, st), mv(v, n, mem, true, st);
     Mirror moa(out_a, n * batch, mem, false, st), mob(out_b, n * batch, mem, false, st);
     if (ma.rc | mb.rc | mv.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
-    StreamWs ws(4 * n * batch * sizeof(u64), st);
-    if (ws.rc != FHE_OK) return ws.rc;
-    u64 *scratch = ws.as<u64>();
-    // acc = (0, v).rotate(-b)   (bootstrapping.rs:91-93)
-    int rc = hipMemsetAsync(moa.d, 0, n * batch * sizeof(u64), st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
-    if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::torus_monomial_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)mv.d, size_t(0), mob.d, (unsigned)n,
-                           batch, (const u64 *)mb.d, size_t(1), 1);
-        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
-    }
-    // fold cmux(brk_i, acc, acc.rotate(a_i))   (94-95)
-    for (size_t i = 0; i < n_lwe && rc == FHE_OK; ++i) rc = launch_cmux(t, brk, i, moa.d, mob.d, batch, ma.d + i, n_lwe, scratch, st);
+    if (batch > 0x7fffffffull || n_lwe > 0x7fffffffull) return FHE_ERR_UNSUPPORTED;
+    // acc = (0, v).rotate(-b), then fold cmux(brk_i, acc, acc.rotate(a_i)) (bootstrapping.rs:91-95): one launch, the
+    // accumulator never leaves the registers of the team that owns the ciphertext
+    int rc = FHE_OK;
+    TORUS_DISPATCH(brk->log_n, {
+        const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<LN>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)),
+                           dim3(fhe::WaveRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
+                           (unsigned)batch, (const u64 *)brk->d_rows[0], (const u64 *)brk->d_rows[1], brk->P, t->T, moa.d, mob.d);
+    });
+    if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
     return rc;

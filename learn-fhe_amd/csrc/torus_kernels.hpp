@@ -91,11 +91,11 @@ __device__ __forceinline__ u64 crt2_mod64(u64 r0, u64 r1, const TorusConsts &T) 
     return upper ? lo - T.P_lo : lo;                            // centred representative, mod 2^64
 }
 
-// One gadget product pass for ONE prime: st = running digit state of (da | db); outputs the residues of
+// One gadget product pass for ONE prime over register-resident operands (coefficient layout): outputs the residues of
 // sum_l rows[l].a * limb_l and sum_l rows[l].b * limb_l (exact integers) mod that prime, coefficient layout.
 template <int LOG_N>
-__device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, const u64 *__restrict__ db, const u64 *__restrict__ rows,
-                                                  const TDecomp &P, u64 p, int lane, u64 *lds, const Barrett &B,
+__device__ __forceinline__ void team_torus_gadget(const u64 (&da)[WaveRing<LOG_N>::E], const u64 (&db)[WaveRing<LOG_N>::E],
+                                                  const u64 *__restrict__ rows, const TDecomp &P, u64 p, int lane, u64 *lds, const Barrett &B,
                                                   const typename ArithPM<60>::K &k, u64 (&sa)[WaveRing<LOG_N>::E],
                                                   u64 (&sb)[WaveRing<LOG_N>::E]) {
     using A = ArithPM<60>;
@@ -106,12 +106,12 @@ __device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, co
     K.B = B;
     u64 st[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = tdecomp_init(da[coef_index<LOG_N>(lane, e)], P); }
+    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = tdecomp_init(da[e], P); }
 #pragma unroll 1
     for (int j = 0; j < 2 * P.d; ++j) {
         if (j == P.d) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) st[e] = tdecomp_init(db[coef_index<LOG_N>(lane, e)], P);
+            for (int e = 0; e < E; ++e) st[e] = tdecomp_init(db[e], P);
         }
         u64 x[E];
 #pragma unroll
@@ -132,72 +132,131 @@ __device__ __forceinline__ void wave_torus_gadget(const u64 *__restrict__ da, co
     }
 }
 
+// c <- c * X^r on the torus (ring.rs:299-313; negation = wrapping_neg), r in [0, 2N), through the team's LDS image
+template <int LOG_N>
+__device__ __forceinline__ void team_torus_rotate(u64 (&c)[WaveRing<LOG_N>::E], unsigned r, int lane, u64 *lds) {
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E, N = W::N;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned pos = (unsigned(coef_index<LOG_N>(lane, e)) + r) & (2 * N - 1);
+        lds[lds_phys(pos & (N - 1))] = pos < N ? c[e] : 0 - c[e];
+    }
+    exchange_sync<W::WAVE>();
+#pragma unroll
+    for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))];
+    exchange_sync<W::WAVE>();
+}
+
+// (xa, xb) <- external_product(key, (da, db)), exact: both primes, then the Chinese remainder mod 2^64
+// (scheme/tfhe/src/tggsw.rs:100-112 for k = 1); everything stays in the team's registers
+template <int LOG_N>
+__device__ __forceinline__ void team_torus_external_product(const u64 (&da)[WaveRing<LOG_N>::E], const u64 (&db)[WaveRing<LOG_N>::E],
+                                                            const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, const TDecomp &P,
+                                                            const TorusConsts &T, int lane, u64 *lds, u64 (&xa)[WaveRing<LOG_N>::E],
+                                                            u64 (&xb)[WaveRing<LOG_N>::E]) {
+    using A = ArithPM<60>;
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E;
+    // the first prime's residues wait in the team's LDS parking area (each lane its own slots: no synchronisation) while the
+    // second prime's pass needs the registers
+    u64 *park = lds + W::PN;
+    {
+        const typename A::K k0 = A::make(T.descs[0], LOG_N, 0, 0);
+        team_torus_gadget<LOG_N>(da, db, rows0, P, T.p0, lane, lds, T.B0, k0, xa, xb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { park[e * W::TEAM + lane] = xa[e]; park[(E + e) * W::TEAM + lane] = xb[e]; }
+    }
+    {
+        const typename A::K k1 = A::make(T.descs[1], LOG_N, 0, 0);
+        team_torus_gadget<LOG_N>(da, db, rows1, P, T.p1, lane, lds, T.B1, k1, xa, xb);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        xa[e] = crt2_mod64(park[e * W::TEAM + lane], xa[e], T);
+        xb[e] = crt2_mod64(park[(E + e) * W::TEAM + lane], xb[e], T);
+    }
+}
+
+// One CMUX step of the blind rotation on a register-resident accumulator (tggsw.rs:114-121, bootstrapping.rs:94-95):
+// acc <- acc + external_product(key, acc X^r - acc); r = 0 leaves acc untouched (the external product of zero is exactly zero)
+template <int LOG_N>
+__device__ __forceinline__ void team_torus_cmux(u64 (&ca)[WaveRing<LOG_N>::E], u64 (&cb)[WaveRing<LOG_N>::E], unsigned r,
+                                                const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, const TDecomp &P,
+                                                const TorusConsts &T, int lane, u64 *lds) {
+    constexpr int E = WaveRing<LOG_N>::E;
+    if (r == 0) return;  // team-uniform
+    u64 da[E], db[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { da[e] = ca[e]; db[e] = cb[e]; }
+    team_torus_rotate<LOG_N>(da, r, lane, lds);
+    team_torus_rotate<LOG_N>(db, r, lane, lds);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
+    u64 xa[E], xb[E];
+    team_torus_external_product<LOG_N>(da, db, rows0, rows1, P, T, lane, lds, xa, xb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { ca[e] += xa[e]; cb[e] += xb[e]; }
+}
+
 // scheme/tfhe/src/tggsw.rs:100-121 for k = 1, one team (fhew_kernels.hpp: WaveRing) per ciphertext.
 //   rot == nullptr: (a, b) <- external_product(key, (a, b))
-//   rot != nullptr: CMUX step of the blind rotation: (a, b) <- (a, b) + external_product(key, (a, b) X^r - (a, b)),
-//                   r = rot[ct * rot_stride] mod 2N  (acc.rotate(a_i), bootstrapping.rs:94-95)
-// scratch: [batch][4][N] u64 (difference polynomials and the first prime's residues)
+//   rot != nullptr: one CMUX step: (a, b) <- (a, b) + external_product(key, (a, b) X^r - (a, b)), r = rot[ct * rot_stride] mod 2N
 template <int LOG_N>
 __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void torus_cmux_kernel(
     u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch, const u64 *__restrict__ rows0, const u64 *__restrict__ rows1,
-    TDecomp P, const u64 *__restrict__ rot, size_t rot_stride, TorusConsts T, u64 *__restrict__ scratch) {
-    using A = ArithPM<60>;
+    TDecomp P, const u64 *__restrict__ rot, size_t rot_stride, TorusConsts T) {
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const unsigned ct = blockIdx.x * W::TEAMS + team;
     if (ct >= batch) return;
-    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::TORUS_LDS_WORDS;
     u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
-    u64 *da = scratch + size_t(ct) * 4 * N, *db = da + N, *r0a = db + N, *r0b = r0a + N;
-    const bool cmux = rot != nullptr;
-    unsigned r = 0;
-    if (cmux) {
-        r = unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1);
-        if (r == 0) return;  // acc X^0 - acc = 0: the external product of zero is exactly zero
+    u64 ca[E], cb[E];
+    wave_load<LOG_N>(ca, ga, lane);
+    wave_load<LOG_N>(cb, gb, lane);
+    if (rot != nullptr) {
+        team_torus_cmux<LOG_N>(ca, cb, unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1), rows0, rows1, P, T, lane, lds);
+    } else {
+        u64 xa[E], xb[E];
+        team_torus_external_product<LOG_N>(ca, cb, rows0, rows1, P, T, lane, lds, xa, xb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { ca[e] = xa[e]; cb[e] = xb[e]; }
     }
-    // difference polynomials (or the ciphertext itself) -> scratch, each lane touching only its own coefficients
+    wave_store<LOG_N>(ca, ga, lane);
+    wave_store<LOG_N>(cb, gb, lane);
+}
+
+// scheme/tfhe/src/bootstrapping.rs:84-96 `blind_rotate` (k = 1), the whole fold in ONE launch: acc = (0, v X^-b), then
+// acc <- cmux(brk_i, acc, acc X^(a_i)) for i = 0 .. n_lwe-1, the accumulator in the team's registers throughout.
+// rows0 / rows1: the key set [n_lwe][2d][2][N] per prime (key_perm layout); a_tilde [batch][n_lwe], b_tilde [batch] mod 2N.
+template <int LOG_N>
+__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void torus_blind_rotate_kernel(
+    const u64 *__restrict__ v, const u64 *__restrict__ a_tilde, const u64 *__restrict__ b_tilde, unsigned n_lwe, unsigned batch,
+    const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, TDecomp P, TorusConsts T, u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    using W = WaveRing<LOG_N>;
+    constexpr int E = W::E, N = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::TORUS_LDS_WORDS;
+    u64 ca[E], cb[E];
+    wave_load<LOG_N>(cb, v, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) ca[e] = 0;
+    team_torus_rotate<LOG_N>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);  // (0, v).rotate(-b)
+    const size_t per = size_t(2 * P.d) * 2 * N;
+    const u64 *a = a_tilde + size_t(ct) * n_lwe;
 #pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        const u64 *src = h ? gb : ga;
-        u64 *dst = h ? db : da;
-        u64 c[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) c[e] = src[coef_index<LOG_N>(lane, e)];
-        if (cmux) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const unsigned pos = (unsigned(coef_index<LOG_N>(lane, e)) + r) & (2 * N - 1);
-                lds[lds_phys(pos & (N - 1))] = pos < N ? c[e] : 0 - c[e];
-            }
-            exchange_sync<W::WAVE>();
-#pragma unroll
-            for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))] - c[e];
-            exchange_sync<W::WAVE>();
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) dst[coef_index<LOG_N>(lane, e)] = c[e];
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const unsigned r = __builtin_amdgcn_readfirstlane(unsigned(a[i]) & (2 * N - 1));
+        team_torus_cmux<LOG_N>(ca, cb, r, rows0 + i * per, rows1 + i * per, P, T, lane, lds);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // own writes, own reads: program order per lane suffices
-    u64 sa[E], sb[E];
-    {
-        const typename A::K k0 = A::make(T.descs[0], LOG_N, 0, 0);
-        wave_torus_gadget<LOG_N>(da, db, rows0, P, T.p0, lane, lds, T.B0, k0, sa, sb);
-#pragma unroll
-        for (int e = 0; e < E; ++e) { r0a[coef_index<LOG_N>(lane, e)] = sa[e]; r0b[coef_index<LOG_N>(lane, e)] = sb[e]; }
-    }
-    {
-        const typename A::K k1 = A::make(T.descs[1], LOG_N, 0, 0);
-        wave_torus_gadget<LOG_N>(da, db, rows1, P, T.p1, lane, lds, T.B1, k1, sa, sb);
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = coef_index<LOG_N>(lane, e);
-        const u64 xa = crt2_mod64(r0a[i], sa[e], T), xb = crt2_mod64(r0b[i], sb[e], T);
-        ga[i] = cmux ? ga[i] + xa : xa;
-        gb[i] = cmux ? gb[i] + xb : xb;
-    }
+    wave_store<LOG_N>(ca, out_a + size_t(ct) * N, lane);
+    wave_store<LOG_N>(cb, out_b + size_t(ct) * N, lane);
 }
 
 // exact torus product building blocks for fhe_torus_mul: c = a * b with |b| small (two-prime CRT)
