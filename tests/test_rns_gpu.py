@@ -1,6 +1,7 @@
 """GPU parity tests for SURVEY.md section 8(a) row a14 (RNS base extension, rescale_k, CKKS key switch) and for
 rings above 2^14 (radix-2^pb pass + 2^14 sub-transforms), bit-exact against the oracle."""
 import math
+import os
 import random
 
 import numpy as np
@@ -161,3 +162,51 @@ def test_rns_evaluation_residency(fhe, cref, torch_cuda, log_n, bits, big_l, big
             assert np.array_equal(prod[1, l], cref.ntt_mul(m, a[1, l], b[1, l], n)), (extended, l)
     with pytest.raises(fhe.FheError):
         rns.ntt_(dev(torch_cuda, rand_limbs(3, qs, 1 << 18, 1)), 1 << 18)  # no 2^19-th root of unity in these primes
+
+
+SHARDED_WORKER = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import learn_fhe_amd as F
+from learn_fhe_amd.shard import GpuLimbOps, ckks_key_switch_limb_sharded, dist_all_gather
+from oracle import cref
+dist.init_process_group(backend="gloo")                    # one GPU on this box: every rank drives cuda:0, gloo carries the gather
+rank, world = dist.get_rank(), dist.get_world_size()
+log_n = %d
+n = 1 << log_n
+primes = cref.two_adic_primes(60, log_n + 1, 2 * world)
+qs, ps = primes[:world], primes[world:]
+rng = np.random.Generator(np.random.PCG64(17))             # same seed on every rank: replicated inputs
+limbs = lambda mods: np.stack([rng.integers(0, m, size=n, dtype=np.uint64) for m in mods])
+ksk_b, ksk_a, ct_b, ct_a = limbs(qs + ps), limbs(qs + ps), limbs(qs), limbs(qs)
+D = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+H = lambda t: t.cpu().numpy().view(np.uint64)
+ops = GpuLimbOps(F, qs, ps, rank)
+all_gather = dist_all_gather
+kq_b, kq_a = ops.key_to_eval("q", D(ksk_b[rank]), n), ops.key_to_eval("q", D(ksk_a[rank]), n)
+kp_b, kp_a = ops.key_to_eval("p", D(ksk_b[world + rank]), n), ops.key_to_eval("p", D(ksk_a[world + rank]), n)
+b, a = ckks_key_switch_limb_sharded(ops, rank, world, n, D(ct_b[rank]), D(ct_a), kq_b, kq_a, kp_b, kp_a, all_gather)
+eb, ea = cref.ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a)
+assert np.array_equal(H(b), eb[rank]) and np.array_equal(H(a), ea[rank]), "limb-sharded key switch != oracle"
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 12), (4, 15)])
+def test_ckks_key_switch_limb_sharded(tmp_path, world, log_n):
+    """SURVEY.md section 8(e) cfg4 partition on the device path: rank r owns q-limb r and p-limb r, ONE all-gather of the p-limb
+    products; `world` processes share this box's GPU (gloo carries the gather), each rank's output limb bit-exact vs the oracle"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER % (ROOT, log_n))
+    port = str(29550 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", port, str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world

@@ -62,3 +62,60 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+CKKS_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from oracle import cref
+    from learn_fhe_amd.shard import ckks_key_switch_limb_sharded
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    log_n, n = 6, 64
+    primes = cref.two_adic_primes(50, log_n + 1, 2 * world)
+    qs, ps = primes[:world], primes[world:]
+    rng = np.random.Generator(np.random.PCG64(7))          # same seed on every rank: replicated inputs
+    limbs = lambda mods: np.stack([rng.integers(0, m, size=n, dtype=np.uint64) for m in mods])
+    ksk_b, ksk_a, ct_b, ct_a = limbs(qs + ps), limbs(qs + ps), limbs(qs), limbs(qs)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+    U = lambda t: t.numpy().view(np.uint64)
+
+    class OracleOps:  # the arithmetic of one rank, from the CPU oracle: this test checks the ORCHESTRATION (who computes what,
+        def extend_to_my_p(self, a_all, n):  # what is exchanged), the GPU arithmetic has its own parity tests
+            return T(cref.rns_extend_bases(qs, [ps[rank]], U(a_all))[0])
+        def key_to_eval(self, which, k, n):
+            return T(cref.ntt_fwd(qs[rank] if which == "q" else ps[rank], U(k), n))
+        def limb_product(self, which, x, key_eval, n):
+            m = qs[rank] if which == "q" else ps[rank]
+            return T(cref.ntt_inv(m, cref.pointwise_mul(m, cref.ntt_fwd(m, U(x), n), U(key_eval)), n))
+        def rescale_my_q(self, x_q, x_p_all, n):
+            return T(cref.rns_rescale_k([qs[rank]] + ps, len(ps), np.concatenate([U(x_q).reshape(1, n), U(x_p_all).reshape(len(ps), n)]))[0])
+        def add_my_q(self, x, y):
+            return T(np.array([(int(p) + int(q)) %% qs[rank] for p, q in zip(U(x), U(y))], dtype=np.uint64))
+
+    ops = OracleOps()
+    def all_gather(x):
+        out = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(out, x.contiguous())
+        return torch.stack(out, dim=0)
+    kq_b, kq_a = ops.key_to_eval("q", T(ksk_b[rank]), n), ops.key_to_eval("q", T(ksk_a[rank]), n)
+    kp_b, kp_a = ops.key_to_eval("p", T(ksk_b[world + rank]), n), ops.key_to_eval("p", T(ksk_a[world + rank]), n)
+    b, a = ckks_key_switch_limb_sharded(ops, rank, world, n, T(ct_b[rank]), T(ct_a), kq_b, kq_a, kp_b, kp_a, all_gather)
+    eb, ea = cref.ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a)
+    assert np.array_equal(U(b), eb[rank]) and np.array_equal(U(a), ea[rank]), "limb-sharded key switch != single-process result"
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_two_rank_gloo_limb_sharded_ckks_key_switch(tmp_path):
+    """SURVEY.md section 8(e), cfg4 partition: rank r owns q-limb r and p-limb r; one all-gather of the p-limb products"""
+    script = tmp_path / "ckks_worker.py"
+    script.write_text(CKKS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

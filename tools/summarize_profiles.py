@@ -45,9 +45,13 @@ summary = {}
 for k, cs in sorted(pmc.items()):
     e = {}
     for c, v in cs.items():
-        e[c + "_raw_avg_KiB"] = sum(v) / len(v)
-        e[c + "_launches"] = len(v)
-        e[c + "_corrected_bytes"] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+        if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            e[c + "_raw_avg_KiB"] = sum(v) / len(v)
+            e[c + "_launches"] = len(v)
+            e[c + "_corrected_bytes"] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+        else:  # SQ / GRBM counters of the stall analysis (tools/scripts/pmc_lab.sh, pmc_fhew.sh): per-launch average
+            e[c + "_avg"] = sum(v) / len(v)
+            e[c + "_launches"] = len(v)
     summary[k] = e
 json.dump(summary, open(os.path.join("profiles", tag + "_pmc.json"), "w"), indent=1)
 print("wrote profiles/%s_pmc.json" % tag)
