@@ -66,7 +66,7 @@ def _timeit(torch, fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def fhew_bench(torch, F, dev, local_rank, batches=(64, 1024), reps=3):
+def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024), reps=3):
     """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
     rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
     N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident; and the
