@@ -97,3 +97,23 @@ def test_host_mirror_of_the_gate_logic(fhe):
     f = ev.table_poly(fhe.Fhew.TABLES["nand"], np.zeros(1, dtype=np.uint64))
     q8 = ev.big_q_by_8
     assert f.shape == (512,) and list(f[:128]) == [q8] * 128 and list(f[384:]) == [268369921 - q8] * 128
+
+
+def test_header_is_plain_c_and_links(tmp_path, fhe):
+    """include/fhe_ring.h is the drop-in boundary: it must compile as C99 (no C++-isms) and every declared function must
+    resolve against the built library from a C translation unit (no compute call: there is no GPU here)."""
+    import re
+    import subprocess
+    header = os.path.join(ROOT, "include", "fhe_ring.h")
+    names = sorted(set(re.findall(r"\b(fhe_[a-z0-9_]+)\s*\(", open(header).read())))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "fhe_ring.h"\n#include <stdio.h>\nint main(void) {\n  void (*f[])(void) = {%s};\n'
+                   '  unsigned n = 0; for (unsigned i = 0; i < sizeof f / sizeof f[0]; ++i) n += f[i] != 0;\n'
+                   '  printf("%%u %%s\\n", n, fhe_version());\n  return 0;\n}\n' % ", ".join("(void (*)(void))%s" % x for x in names))
+    lib_dir = os.path.dirname(fhe.lib_path())
+    exe = tmp_path / "abi"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", lib_dir,
+           "-lfhe_ring", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert len(names) >= 50
