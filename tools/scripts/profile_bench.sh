@@ -6,7 +6,8 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-fhew --steps 10 --warmup 2"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_stats.log 2>&1
+# kernel-trace stats of THE default bench command (what the driver runs); the counter passes below use a short run
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py > $R/gpurun_out/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_pmc_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_pmc_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_pmc_write.log 2>&1
 if [ -x $R/tools/lab ]; then
