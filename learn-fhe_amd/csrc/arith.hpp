@@ -39,6 +39,7 @@ struct ModDesc {
     u64 q;
     const TwPair *tw, *twi;
     u64 ninv[20], ninv_s[20];  // (2^k)^-1 mod q and its Shoup companion, k = log2 N
+    u64 ninv_w[20], ninv_w_s[20];  // (2^k)^-1 * twi[1] mod q (+ companion): the last inverse layer's twiddle with n^-1 folded in
     u64 one_s;                 // floor(2^64 / q): Shoup companion of 1
     // pseudo-Mersenne fast path: q = 2^pm_b - pm_c, twiddles in the packed 8-byte PmRaw form; pm_b = 0: not eligible
     const u64 *tww, *twwi;
@@ -52,9 +53,23 @@ struct ArithShoup {
         const FHE_GLOBAL TwPair *tw, *twi;
         u64 ninv, ninv_s;
         int pb, prefix;
+        TwPair ninv_w;  // n^-1 * twi[1] (whole rings only, pb = 0)
     };
     static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
-        return K{D.q, 2 * D.q, as_global(D.tw), as_global(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix};
+        return K{D.q, 2 * D.q, as_global(D.tw), as_global(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix,
+                 TwPair{D.ninv_w[log_n_total], D.ninv_w_s[log_n_total]}};
+    }
+    // The LAST inverse layer of a whole ring with n^-1 folded in (util/src/ring/fft.rs:59-77: layer 0, then `* n_inv`): the
+    // difference branch takes twi[1] n^-1 as its twiddle, only the sum branch still needs a product.  Canonical outputs.
+    static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
+        const u64 s = X + Y, d = X - Y + k.q2;
+        X = csub(mul_shoup_lazy(s, k.ninv, k.ninv_s, k.q), k.q);
+        Y = csub(mul_shoup_lazy(d, k.ninv_w.w, k.ninv_w.ws, k.q), k.q);
+    }
+    // ... and of a sub-transform (pb > 0: no scaling here): an ordinary butterfly, canonical outputs
+    static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const TwPair &p, const K &k) {
+        gs_bfly(X, Y, p.w, p.ws, k.q, k.q2);
+        X = csub(X, k.q); Y = csub(Y, k.q);
     }
     // twiddles: TwRaw is what a load brings from HBM/L2, TwReg what a butterfly consumes (prep() converts, once per twiddle)
     typedef TwPair TwRaw;
@@ -144,7 +159,8 @@ struct ArithPM {
     struct K {
         PmK m;
         const FHE_GLOBAL PmRaw *tw, *twi;
-        PmTw ninv;  // n^-1 (or 1) in twiddle form
+        PmTw ninv;    // n^-1 (or 1) in twiddle form
+        PmTw ninv_w;  // n^-1 * twi[1] (whole rings only, pb = 0)
         int pb, prefix;
     };
     typedef PmRaw TwRaw;
@@ -176,6 +192,7 @@ struct ArithPM {
         k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c;
         k.tw = (const FHE_GLOBAL PmRaw *)D.tww; k.twi = (const FHE_GLOBAL PmRaw *)D.twwi;
         k.ninv = split(pb ? 1 : D.ninv[log_n_total]);
+        k.ninv_w = split(D.ninv_w[log_n_total]);
         k.pb = pb; k.prefix = prefix;
         return k;
     }
@@ -200,6 +217,17 @@ struct ArithPM {
         Y = pm_mul<B>(d, w, k.m);
     }
     static constexpr bool GS_FOLDS = true;
+    // last inverse layer, n^-1 folded in (see ArithShoup::gs_last_scaled); PH = 1 inputs (sums < 2q +, products < q +)
+    static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
+        const u64 s = X + Y, d = X - Y + k.m.q4;
+        X = csub(pm_mul<B>(s, k.ninv, k.m), k.m.q);
+        Y = csub(pm_mul<B>(d, k.ninv_w, k.m), k.m.q);
+    }
+    static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const PmTw &w, const K &k) {
+        const u64 s = X + Y, d = X - Y + k.m.q4;
+        X = csub(fold1(s, k.m), k.m.q);
+        Y = csub(pm_mul<B>(d, w, k.m), k.m.q);
+    }
     // forward layers between two folds: inputs < q + eps, a multiplicand of layer L is < (2L - 1) q and must be < 2^63
     static constexpr int CT_LAYERS = ((1 << (63 - B)) + 1) / 2 > 64 ? 64 : ((1 << (63 - B)) + 1) / 2;
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }

@@ -18,6 +18,7 @@ struct fhe_ctx {
     int log_cap = 0;     // tables hold 2^log_cap entries = min(2^(s-1), 2^FHE_MAX_LOG_N)
     std::vector<uint64_t> tw, twi;  // reference layout: entry j = omega^(+-bitrev_{s-1}(j))
     uint64_t ninv[32] = {0}, ninv_s[32] = {0};  // (2^k)^-1 mod q and its Shoup companion
+    uint64_t ninv_w[32] = {0}, ninv_w_s[32] = {0};  // (2^k)^-1 * twi[1] mod q and its Shoup companion
     fhe::Barrett barrett{};
     int device = -1;
     fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_fwd_kernel(u64 *__restri
     ntt14_fwd_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
 }
 
-template <class A>
+template <class A, bool PFX>
 __device__ __forceinline__ void ntt14_inv_body(u64 *__restrict__ g, const typename A::K &k, u64 *lds, const int t) {
     using namespace n14;
     u64 x[32];
@@ -383,14 +383,31 @@ __device__ __forceinline__ void ntt14_inv_body(u64 *__restrict__ g, const typena
     xchg_10(x, t, lds);
     istep<A, P0<3>, P0<2>>(x, ta, tb, 0, 0, k);
     istep<A, P0<2>, P0<1>>(x, tb, ta, 0, 0, k);
-    istep<A, P0<1>, P0<0>>(x, ta, tb, 0, 0, k);
-    istep<A, P0<0>, void>(x, tb, ta, 0, 0, k);
+    // the last layer leaves canonical values: a whole ring folds n^-1 into it (the difference branch multiplies by
+    // twi[1] n^-1, only the sum branch needs a product of its own: 16 products fewer than layer + scaling), a sub-transform of a
+    // larger ring is not scaled here at all
+    istep<A, P0<1>, typename std::conditional<PFX, P0<0>, void>::type>(x, ta, tb, 0, 0, k);
+    typename A::TwReg w{};
+    if constexpr (PFX) {
+        FHE_SCHED_FENCE();
+        if constexpr (!ahead<A, P0<0>>()) tw_load<A, true, P0<0>>(tb, 0, k);
+        w = A::prep(tb[0]);
+    }
+    // four butterflies at a time, stored as they finish (an unfenced block of 16 independent butterflies is scheduled
+    // for maximum overlap and spills 100 registers)
+    static_for<0, 4>([&](auto cc) {
+        constexpr int base = (decltype(cc)::value & 1) * 4 + (decltype(cc)::value >> 1) * 16;
+        FHE_SCHED_FENCE();
 #pragma unroll
-    for (int r = 0; r < 32; ++r) g[((r & 15) << 10) | ((r >> 4) << 9) | t] = A::finish_inv(x[r], k);
+        for (int o = base; o < base + 4; ++o) {
+            if constexpr (PFX) A::gs_last_plain(x[o], x[o + 8], w, k);
+            else A::gs_last_scaled(x[o], x[o + 8], k);
+            g[((o & 15) << 10) | ((o >> 4) << 9) | t] = x[o];
+            g[(((o + 8) & 15) << 10) | ((o >> 4) << 9) | t] = x[o + 8];
+        }
+    });
 }
 
-// PFX = false: a whole 2^14 ring (pb = 0): the block prefix and the table offset are compile-time zeros, which takes the
-// variable shifts out of every twiddle index.  PFX = true: sub-transform sub & (2^pb - 1) of polynomial sub >> pb.
 template <class A, bool PFX>
 __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                     unsigned n_desc, unsigned subs, int pb) {
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(N14_THREADS, 4) void ntt14_inv_kernel(u64 *__restri
     const unsigned poly = PFX ? sub >> pb : sub;
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
-    ntt14_inv_body<A>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
+    ntt14_inv_body<A, PFX>(data + (size_t(sub) << 14), k, lds, threadIdx.x);
 }
 
 }  // namespace fhe

@@ -168,6 +168,8 @@ int ctx_build_host(uint64_t q, fhe_ctx *c) {
         uint64_t n = (uint64_t(1) << k) % q;
         c->ninv[k] = n ? invmod(n, q) : 0;
         c->ninv_s[k] = shoup(c->ninv[k], q);
+        c->ninv_w[k] = (n && c->twi.size() > 1) ? mulmod(c->ninv[k], c->twi[1], q) : 0;
+        c->ninv_w_s[k] = shoup(c->ninv_w[k], q);
     }
     int nbits = 64 - __builtin_clzll(q);
     // pseudo-Mersenne eligibility (ntt14.hpp): q = 2^b - c with 33 <= b <= 60 and c <= 2^(b-33)
@@ -239,7 +241,10 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
         c->h_desc.q = q;
         c->h_desc.tw = c->d_tw;
         c->h_desc.twi = c->d_twi;
-        for (int k = 0; k < 20; ++k) { c->h_desc.ninv[k] = c->ninv[k]; c->h_desc.ninv_s[k] = c->ninv_s[k]; }
+        for (int k = 0; k < 20; ++k) {
+            c->h_desc.ninv[k] = c->ninv[k]; c->h_desc.ninv_s[k] = c->ninv_s[k];
+            c->h_desc.ninv_w[k] = c->ninv_w[k]; c->h_desc.ninv_w_s[k] = c->ninv_w_s[k];
+        }
         c->h_desc.one_s = fhe::shoup(1, q);
         if (e == hipSuccess) e = hipMalloc(&c->d_desc, sizeof(fhe::ModDesc));
         if (e == hipSuccess) e = hipMemcpy(c->d_desc, &c->h_desc, sizeof(fhe::ModDesc), hipMemcpyHostToDevice);

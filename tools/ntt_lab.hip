@@ -119,7 +119,8 @@ int main(int argc, char **argv) {
     hipMemcpy(d_twi, twi.data(), cap * sizeof(TwPair), hipMemcpyHostToDevice);
     ModDesc hd{};
     hd.q = q; hd.tw = d_tw; hd.twi = d_twi; hd.one_s = shoup(1, q);
-    for (int k = 0; k < 20; ++k) { hd.ninv[k] = invmod((u64(1) << k) % q, q); hd.ninv_s[k] = shoup(hd.ninv[k], q); }
+    for (int k = 0; k < 20; ++k) { hd.ninv[k] = invmod((u64(1) << k) % q, q); hd.ninv_s[k] = shoup(hd.ninv[k], q);
+                                  hd.ninv_w[k] = mulmod(hd.ninv[k], twi[1].w, q); hd.ninv_w_s[k] = shoup(hd.ninv_w[k], q); }
     {   // pseudo-Mersenne tables (q = 2^60 - 98303)
         std::vector<u64> w(cap), wi(cap);
         for (size_t j = 0; j < cap; ++j) { w[j] = ArithPM<60>::pack(tw[j].w); wi[j] = ArithPM<60>::pack(twi[j].w); }
@@ -144,7 +145,6 @@ int main(int argc, char **argv) {
     V14 v14[] = {
         {"ntt14 Shoup (512 thr, 2 WG/CU)", ntt14_fwd_kernel<ArithShoup, false>, ntt14_inv_kernel<ArithShoup, false>},
         {"ntt14 pseudo-Mersenne", ntt14_fwd_kernel<ArithPM<60>, false>, ntt14_inv_kernel<ArithPM<60>, false>},
-        {"ntt14 pseudo-Mersenne, PFX build", ntt14_fwd_kernel<ArithPM<60>, true>, ntt14_inv_kernel<ArithPM<60>, true>},
         {"ntt14 ablation: no butterflies", ntt14_fwd_kernel<ArithNone, false>, ntt14_inv_kernel<ArithNone, false>},
         {"ntt14 ablation: no twiddle loads", ntt14_fwd_kernel<ArithNoTw, false>, ntt14_inv_kernel<ArithNoTw, false>},
         {"ntt14 pseudo-Mersenne, twiddle prefetch", ntt14_fwd_kernel<ArithPrefetch, false>, ntt14_inv_kernel<ArithPrefetch, false>},
