@@ -234,13 +234,15 @@ struct ArithPM {
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(pm_mul<B>(x, k.ninv, k.m), k.m.q); }
-    // multiply-accumulate against a variable operand: the key value is split on the fly (4 instructions), the lazy
+    // multiply-accumulate against a key value (stored pre-split: one shift completes the operand), the lazy
     // forward output (< 2^63) is the multiplicand as it stands, products (< 1.25 * 2^B) are summed without reduction and
     // the running sum is folded every MAC_FOLD terms so it never reaches 2^64
     static constexpr int MAC_FOLD = ((1 << (64 - B)) * 4 / 5 - 2) < 1 ? 1 : (((1 << (64 - B)) * 4 / 5 - 2) > 64 ? 64 : ((1 << (64 - B)) * 4 / 5 - 2));
     static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }
+    // kval arrives in the packed operand form (prepared keys are stored that way: fhew_kernels.hpp key_permute_kernel)
     static __device__ __forceinline__ u64 mac(u64 acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
-        u64 s = acc + pm_mul<B>(xin, split(kval), k.m);
+        const unsigned wl = (unsigned)kval;
+        u64 s = acc + pm_mul<B>(xin, PmTw{wl, wl << (63 - B), (unsigned)(kval >> 32)}, k.m);
         if ((term % MAC_FOLD) == MAC_FOLD - 1) s = fold1(s, k.m);
         return s;
     }

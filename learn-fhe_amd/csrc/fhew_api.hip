@@ -111,7 +111,8 @@ int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uin
     // rows -> evaluation domain once (what Rgsw::internal_product does per call, rgsw.rs:136-138)
     if (rc == FHE_OK) rc = fhe::ntt_fwd_device(ctx, ta, log_n, 2 * rows, st);
     if (rc == FHE_OK) {
-        FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows));
+        FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows,
+                                                 use_pm54(ctx, log_n) ? 54 : 0));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;

@@ -343,17 +343,25 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
     wave_store<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
 }
 
-// evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout
+// evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout;
+// pm_b != 0: values stored in the pseudo-Mersenne policy's packed operand form {w mod 2^(b-31), w >> (b-31)} (arith.hpp), so
+// the multiply-accumulate reads both words of its fixed operand straight from the load
 template <int LOG_N>
-FHE_HEADER_KERNEL void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows) {
+FHE_HEADER_KERNEL void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows, int pm_b) {
     constexpr int N = 1 << LOG_N;
     const size_t total = rows * N;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t row = idx >> LOG_N;
         const int e = int(idx & (N - 1));
         const int p = key_perm<LOG_N>(e);
-        out[(row * 2 + 0) * N + p] = in_a[idx];
-        out[(row * 2 + 1) * N + p] = in_b[idx];
+        u64 va = in_a[idx], vb = in_b[idx];
+        if (pm_b) {
+            const u64 lo_mask = (u64(1) << (pm_b - 31)) - 1;
+            va = ((va >> (pm_b - 31)) << 32) | (va & lo_mask);
+            vb = ((vb >> (pm_b - 31)) << 32) | (vb & lo_mask);
+        }
+        out[(row * 2 + 0) * N + p] = va;
+        out[(row * 2 + 1) * N + p] = vb;
     }
 }
 

@@ -207,7 +207,7 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
         rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
         if (rc != FHE_OK) break;
         TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
-                                                 (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows));
+                                                 (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows, 60));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
