@@ -93,6 +93,8 @@ struct ArithShoup {
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(mul_shoup_lazy(x, k.ninv, k.ninv_s, k.q), k.q); }
     // evaluation-domain multiply-accumulate against a VARIABLE operand (key rows): x = forward-transform output (lazy)
+    typedef u64 MacAcc;
+    static __device__ __forceinline__ MacAcc mac_zero() { return 0; }
     static __device__ __forceinline__ u64 mac_in(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
     static __device__ __forceinline__ u64 mac(u64 acc, u64 xin, u64 kval, int, const K &k, const Barrett &B) {
         return csub(acc + mulmod_barrett(xin, kval, B), k.q);
@@ -137,19 +139,32 @@ __device__ __forceinline__ u64 hi_word(u64 x) {
     return d;
 }
 
+// w y = v + u 2c (mod q), unreduced: v < 2^(B+2), u < wh y1 + 2^32
 template <int B>
-__device__ __forceinline__ u64 pm_mul(u64 y, const PmTw w, const PmK &k) {
-    constexpr unsigned HMASK = (1u << (B - 32)) - 1;
+__device__ __forceinline__ void pm_mul_vu(u64 y, const PmTw w, u64 &v, u64 &u) {
     const unsigned y0 = (unsigned)y, y1 = (unsigned)(y >> 32);
     const u64 z0 = (u64)w.wl * y0;
     const u64 z1 = (u64)w.wh * y0 + (u64)w.wlp * y1;
-    const u64 v = mad_u64((unsigned)z1, 1u << (B - 31), z0);
-    const u64 u = (u64)w.wh * y1 + hi_word(z1);
+    v = mad_u64((unsigned)z1, 1u << (B - 31), z0);
+    u = (u64)w.wh * y1 + hi_word(z1);
+}
+
+// v + u 2c folded once at bit B (v + u 2c < 2^96, u < 2^63): < 2^B + 2^(bits(v + u 2c) - B + bits(c))
+template <int B>
+__device__ __forceinline__ u64 pm_reduce_vu(u64 v, u64 u, const PmK &k) {
+    constexpr unsigned HMASK = (1u << (B - 32)) - 1;
     const u64 r1 = (u64)(unsigned)u * k.c2 + v;
     const u64 r2 = (u64)(unsigned)(u >> 32) * k.c2 + (r1 >> 32);  // v + u 2c = r2 * 2^32 + lo32(r1)
     const unsigned h2 = (unsigned)(r2 >> (B - 32));
     const u64 l2 = ((u64)((unsigned)r2 & HMASK) << 32) | (unsigned)r1;
     return (u64)h2 * k.c + l2;
+}
+
+template <int B>
+__device__ __forceinline__ u64 pm_mul(u64 y, const PmTw w, const PmK &k) {
+    u64 v, u;
+    pm_mul_vu<B>(y, w, v, u);
+    return pm_reduce_vu<B>(v, u, k);
 }
 
 // B = bit length of q (compile time: every shift and mask is an immediate)
@@ -234,19 +249,40 @@ struct ArithPM {
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(pm_mul<B>(x, k.ninv, k.m), k.m.q); }
-    // multiply-accumulate against a key value (stored pre-split: one shift completes the operand), the lazy
-    // forward output (< 2^63) is the multiplicand as it stands, products (< 1.25 * 2^B) are summed without reduction and
-    // the running sum is folded every MAC_FOLD terms so it never reaches 2^64
+    // Multiply-accumulate against key values (stored pre-split: one shift completes the operand); the lazy forward output
+    // (< 2^63) is the multiplicand as it stands.
+    //  * B <= 56 (DEFER): the products stay UNREDUCED -- each term adds its (v, u) pair (w y = v + u 2c) to a pair of 64-bit
+    //    sums, and ONE reduction per output runs in mac_finish: 6 instructions + 2 adds per term instead of 12 + 1.  Bounds:
+    //    multiplicands are last-pass outputs < 11 q < 2^(B+4), so u < 2^(B+3) + 2^32, v < 2^(B+2); MAC_TERMS terms keep
+    //    sum u < 2^63 and sum v < 2^62, and v + u 2c < 2^(64 + bits(2c)) folds to < 2^B + 2^(B-10).
+    //  * B > 56: u alone can reach 2^62, so every product is reduced (< 1.25 * 2^B) and only the reduced sums are lazy,
+    //    folded every MAC_FOLD terms.
+    static constexpr bool DEFER = B <= 56;
+    static constexpr int MAC_TERMS = DEFER ? (1 << (59 - B > 6 ? 6 : 59 - B)) : 0;  // 2^(63 - (B + 4)) capped at 64
     static constexpr int MAC_FOLD = ((1 << (64 - B)) * 4 / 5 - 2) < 1 ? 1 : (((1 << (64 - B)) * 4 / 5 - 2) > 64 ? 64 : ((1 << (64 - B)) * 4 / 5 - 2));
+    struct MacPair { u64 v, u; };
+    typedef typename std::conditional<DEFER, MacPair, u64>::type MacAcc;
+    static __device__ __forceinline__ MacAcc mac_zero() { return MacAcc{}; }
     static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }
-    // kval arrives in the packed operand form (prepared keys are stored that way: fhew_kernels.hpp key_permute_kernel)
-    static __device__ __forceinline__ u64 mac(u64 acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
+    static __device__ __forceinline__ MacAcc mac(MacAcc acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
         const unsigned wl = (unsigned)kval;
-        u64 s = acc + pm_mul<B>(xin, PmTw{wl, wl << (63 - B), (unsigned)(kval >> 32)}, k.m);
-        if ((term % MAC_FOLD) == MAC_FOLD - 1) s = fold1(s, k.m);
-        return s;
+        const PmTw w{wl, wl << (63 - B), (unsigned)(kval >> 32)};
+        if constexpr (DEFER) {
+            u64 v, u;
+            pm_mul_vu<B>(xin, w, v, u);
+            acc.v += v; acc.u += u;
+            if ((term % MAC_TERMS) == MAC_TERMS - 1) acc = MacPair{pm_reduce_vu<B>(acc.v, acc.u, k.m), 0};  // (never at the BASELINE shapes)
+            return acc;
+        } else {
+            u64 s = acc + pm_mul<B>(xin, w, k.m);
+            if ((term % MAC_FOLD) == MAC_FOLD - 1) s = fold1(s, k.m);
+            return s;
+        }
     }
-    static __device__ __forceinline__ u64 mac_finish(u64 acc, const K &k) { return fold1(acc, k.m); }  // < 2^B + eps
+    static __device__ __forceinline__ u64 mac_finish(MacAcc acc, const K &k) {  // < 2^B + eps: valid inverse input
+        if constexpr (DEFER) return pm_reduce_vu<B>(acc.v, acc.u, k.m);
+        else return fold1(acc, k.m);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------

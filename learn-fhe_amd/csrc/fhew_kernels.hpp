@@ -219,7 +219,8 @@ struct RingConsts {
 
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
 template <class A, int LOG_N>
-__device__ __forceinline__ void mac_row(const u64 (&x)[WaveRing<LOG_N>::E], u64 (&sa)[WaveRing<LOG_N>::E], u64 (&sb)[WaveRing<LOG_N>::E],
+__device__ __forceinline__ void mac_row(const u64 (&x)[WaveRing<LOG_N>::E], typename A::MacAcc (&sa)[WaveRing<LOG_N>::E],
+                                        typename A::MacAcc (&sb)[WaveRing<LOG_N>::E],
                                         const u64 *__restrict__ row, int lane, int term, const RingConsts &K, const typename A::K &k) {
     constexpr int E = WaveRing<LOG_N>::E, N = 1 << LOG_N, TEAM = WaveRing<LOG_N>::TEAM;
     const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
@@ -248,9 +249,10 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E
                                                     u64 *lds, const RingConsts &K, const typename A::K &k) {
     using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
+    typename A::MacAcc ma[E], mb[E];
     u64 sa[E], sb[E], st[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = decomp_init(ca[e], P); }
+    for (int e = 0; e < E; ++e) { ma[e] = mb[e] = A::mac_zero(); st[e] = decomp_init(ca[e], P); }
     const int total = both ? 2 * P.d : P.d;
 #pragma unroll 1
     for (int j = 0; j < total; ++j) {
@@ -262,10 +264,10 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
         fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        mac_row<A, LOG_N>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(sa[e], k); sb[e] = A::mac_finish(sb[e], k); }
+    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {

@@ -104,9 +104,10 @@ __device__ __forceinline__ void team_torus_gadget(const u64 (&da)[WaveRing<LOG_N
     RingConsts K;
     K.desc = nullptr;
     K.B = B;
+    typename A::MacAcc ma[E], mb[E];
     u64 st[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = tdecomp_init(da[e], P); }
+    for (int e = 0; e < E; ++e) { ma[e] = mb[e] = A::mac_zero(); st[e] = tdecomp_init(da[e], P); }
 #pragma unroll 1
     for (int j = 0; j < 2 * P.d; ++j) {
         if (j == P.d) {
@@ -120,10 +121,10 @@ __device__ __forceinline__ void team_torus_gadget(const u64 (&da)[WaveRing<LOG_N
             x[e] = (long long)dg < 0 ? p - (0 - dg) : dg;  // |digit| <= 2^(log_b-1) < p
         }
         fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, LOG_N>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        mac_row<A, LOG_N>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(sa[e], k); sb[e] = A::mac_finish(sb[e], k); }
+    for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
         inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
