@@ -250,39 +250,27 @@ struct ArithPM {
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(pm_mul<B>(x, k.ninv, k.m), k.m.q); }
     // Multiply-accumulate against key values (stored pre-split: one shift completes the operand); the lazy forward output
-    // (< 2^63) is the multiplicand as it stands.
-    //  * B <= 56 (DEFER): the products stay UNREDUCED -- each term adds its (v, u) pair (w y = v + u 2c) to a pair of 64-bit
-    //    sums, and ONE reduction per output runs in mac_finish: 6 instructions + 2 adds per term instead of 12 + 1.  Bounds:
-    //    multiplicands are last-pass outputs < 11 q < 2^(B+4), so u < 2^(B+3) + 2^32, v < 2^(B+2); MAC_TERMS terms keep
-    //    sum u < 2^63 and sum v < 2^62, and v + u 2c < 2^(64 + bits(2c)) folds to < 2^B + 2^(B-10).
-    //  * B > 56: u alone can reach 2^62, so every product is reduced (< 1.25 * 2^B) and only the reduced sums are lazy,
-    //    folded every MAC_FOLD terms.
-    static constexpr bool DEFER = B <= 56;
-    static constexpr int MAC_TERMS = DEFER ? (1 << (59 - B > 6 ? 6 : 59 - B)) : 0;  // 2^(63 - (B + 4)) capped at 64
-    static constexpr int MAC_FOLD = ((1 << (64 - B)) * 4 / 5 - 2) < 1 ? 1 : (((1 << (64 - B)) * 4 / 5 - 2) > 64 ? 64 : ((1 << (64 - B)) * 4 / 5 - 2));
-    struct MacPair { u64 v, u; };
-    typedef typename std::conditional<DEFER, MacPair, u64>::type MacAcc;
-    static __device__ __forceinline__ MacAcc mac_zero() { return MacAcc{}; }
+    // (< 2^63) is the multiplicand as it stands.  The products stay UNREDUCED: each term adds its (v, u) pair (w y = v + u 2c)
+    // to a pair of 64-bit sums and ONE reduction per MAC_TERMS terms (and one in mac_finish) folds them: 6 instructions + 2
+    // adds per term instead of 12 + 1.  Bounds: v < 2^(B+2); u < 2^31 y1 + 2^32 with y1 = multiplicand >> 32.
+    //  * B <= 56: multiplicands are last-pass outputs < 11 q < 2^(B+4), so u < 2^(B+3) + 2^32: 32 terms keep sum u < 2^63,
+    //    sum v < 2^62.
+    //  * B > 56: multiplicands < 2^63, u < 2^62 + 2^32: 3 terms keep sum u < 2^64 and sum v < 2^64 - 2^50.
+    // In both cases v + u 2c < 2^(65 + bits(c)) folds to < 2^B + 2^(2 bits(c) + 6) = q + eps.
+    static constexpr int MAC_TERMS = B <= 56 ? 32 : 3;
+    struct MacAcc { u64 v, u; };
+    static __device__ __forceinline__ MacAcc mac_zero() { return MacAcc{0, 0}; }
     static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }
     static __device__ __forceinline__ MacAcc mac(MacAcc acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
         const unsigned wl = (unsigned)kval;
         const PmTw w{wl, wl << (63 - B), (unsigned)(kval >> 32)};
-        if constexpr (DEFER) {
-            u64 v, u;
-            pm_mul_vu<B>(xin, w, v, u);
-            acc.v += v; acc.u += u;
-            if ((term % MAC_TERMS) == MAC_TERMS - 1) acc = MacPair{pm_reduce_vu<B>(acc.v, acc.u, k.m), 0};  // (never at the BASELINE shapes)
-            return acc;
-        } else {
-            u64 s = acc + pm_mul<B>(xin, w, k.m);
-            if ((term % MAC_FOLD) == MAC_FOLD - 1) s = fold1(s, k.m);
-            return s;
-        }
+        u64 v, u;
+        pm_mul_vu<B>(xin, w, v, u);
+        acc.v += v; acc.u += u;
+        if ((term % MAC_TERMS) == MAC_TERMS - 1) acc = MacAcc{pm_reduce_vu<B>(acc.v, acc.u, k.m), 0};
+        return acc;
     }
-    static __device__ __forceinline__ u64 mac_finish(MacAcc acc, const K &k) {  // < 2^B + eps: valid inverse input
-        if constexpr (DEFER) return pm_reduce_vu<B>(acc.v, acc.u, k.m);
-        else return fold1(acc, k.m);
-    }
+    static __device__ __forceinline__ u64 mac_finish(MacAcc acc, const K &k) { return pm_reduce_vu<B>(acc.v, acc.u, k.m); }  // < q + eps
 };
 
 // ---------------------------------------------------------------------------------------------------------
