@@ -22,6 +22,7 @@ struct fhe_key {
     int rows_per_ct = 0;  // 2d (RGSW) or d (key-switching key)
     size_t count = 0;
     u64 *d_rows = nullptr;  // [count][rows_per_ct][2][N], evaluation domain, key_perm layout
+    u64 *d_rows_small = nullptr;  // N >= 1024: the same rows in the layout of the small-batch kernels (4 coefficients per lane)
     fhe::DecompParams P{};
 };
 
@@ -111,24 +112,39 @@ int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uin
     // rows -> evaluation domain once (what Rgsw::internal_product does per call, rgsw.rs:136-138)
     if (rc == FHE_OK) rc = fhe::ntt_fwd_device(ctx, ta, log_n, 2 * rows, st);
     if (rc == FHE_OK) {
-        FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows,
+        FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<fhe::WaveRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows,
                                                  use_pm54(ctx, log_n) ? 54 : 0));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
+    u64 *dst_small = nullptr;
+    if (rc == FHE_OK && log_n >= 10) {
+        if (hipMalloc((void **)&dst_small, 2 * words * sizeof(u64)) != hipSuccess) rc = FHE_ERR_HIP;
+        if (rc == FHE_OK) {
+            const int pm = use_pm54(ctx, log_n) ? 54 : 0;
+            if (log_n == 10) hipLaunchKernelGGL((fhe::key_permute_kernel<fhe::WaveRing<10, 2>>), dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst_small, rows, pm);
+            else hipLaunchKernelGGL((fhe::key_permute_kernel<fhe::WaveRing<11, 2>>), dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst_small, rows, pm);
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+    }
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
     (void)hipFree(ta);
-    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); return rc; }
+    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); if (dst_small) (void)hipFree(dst_small); return rc; }
     fhe_key *k = new (std::nothrow) fhe_key();
-    if (!k) { (void)hipFree(dst); return FHE_ERR_INVALID; }
+    if (!k) { (void)hipFree(dst); if (dst_small) (void)hipFree(dst_small); return FHE_ERR_INVALID; }
     k->ctx = ctx; k->log_n = log_n; k->log_b = log_b; k->d = d; k->rows_per_ct = rows_per_ct; k->count = count;
-    k->d_rows = dst; k->P = P;
+    k->d_rows = dst; k->d_rows_small = dst_small; k->P = P;
     *out = k;
     return FHE_OK;
 }
 
-fhe::FhewKey key_view(const fhe_key *k) {
+// Batches up to this size run the 4-coefficients-per-lane instantiation at N >= 1024 (4 / 8 waves per ciphertext): measured at
+// cfg3 +57 % at batch 1 and 64 (120 vs 77, 7.6 k vs 4.8 k blind rotations/s), -2 % at batch 1024 where the GPU is full either way
+constexpr size_t FHEW_SMALL_BATCH = 512;
+inline bool small_shape(int log_n, size_t batch) { return log_n >= 10 && batch <= FHEW_SMALL_BATCH; }
+
+fhe::FhewKey key_view(const fhe_key *k, bool small = false) {
     fhe::FhewKey v;
-    v.rows = k->d_rows;
+    v.rows = small ? k->d_rows_small : k->d_rows;
     v.rows_per_ct = k->rows_per_ct;
     v.P = k->P;
     return v;
@@ -207,6 +223,7 @@ void fhe_key_destroy(fhe_key *k) {
     if (k->ctx && k->ctx->device >= 0) {
         DeviceGuard guard(k->ctx->device);
         if (k->d_rows) (void)hipFree(k->d_rows);
+        if (k->d_rows_small) (void)hipFree(k->d_rows_small);
     }
     delete k;
 }
@@ -229,24 +246,41 @@ static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bo
     }
     Mirror ma(ct_a, n * batch, mem, true, st), mb(ct_b, n * batch, mem, true, st);
     if (ma.rc != FHE_OK || mb.rc != FHE_OK) return FHE_ERR_HIP;
-#define GP_LAUNCH(AR, LN)                                                                                              \
-    {                                                                                                                  \
-        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;                                \
-        rc = set_lds(fhe::gadget_product_kernel<AR, LN>, lds);                                                          \
-        if (rc != FHE_OK) return rc;                                                                                    \
-        hipLaunchKernelGGL((fhe::gadget_product_kernel<AR, LN>), dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, ma.d, \
-                           mb.d, (unsigned)batch, key_view(key), (unsigned)index, both ? 1u : 0u, tt, ring_consts(ctx, LN)); \
+    const bool small = small_shape(key->log_n, batch);
+#define GP_LAUNCH_W(AR, WR)                                                                                                  \
+    {                                                                                                                        \
+        const size_t lds = WR::LDS_BYTES;                                                                                    \
+        rc = set_lds(fhe::gadget_product_kernel<AR, WR>, lds);                                                               \
+        if (rc != FHE_OK) return rc;                                                                                         \
+        hipLaunchKernelGGL((fhe::gadget_product_kernel<AR, WR>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)),      \
+                           dim3(WR::THREADS), lds, st, ma.d, mb.d, (unsigned)batch, key_view(key, small), (unsigned)index,   \
+                           both ? 1u : 0u, tt, ring_consts(ctx, 0));                                                         \
+    }
+#define GP_LAUNCH(AR, LN) GP_LAUNCH_W(AR, fhe::WaveRing<LN>)
+#define GP_LAUNCH_BIG(AR, LN)                                                                \
+    {                                                                                        \
+        if (small) { typedef fhe::WaveRing<LN, 2> WS; GP_LAUNCH_W(AR, WS) }                  \
+        else { typedef fhe::WaveRing<LN> WD; GP_LAUNCH_W(AR, WD) }                           \
     }
     if (use_pm54(ctx, key->log_n)) {
         switch (key->log_n) {
             case 9: GP_LAUNCH(fhe::ArithPM<54>, 9) break;
-            case 10: GP_LAUNCH(fhe::ArithPM<54>, 10) break;
-            case 11: GP_LAUNCH(fhe::ArithPM<54>, 11) break;
+            case 10: GP_LAUNCH_BIG(fhe::ArithPM<54>, 10) break;
+            case 11: GP_LAUNCH_BIG(fhe::ArithPM<54>, 11) break;
             default: return FHE_ERR_UNSUPPORTED;
         }
     } else {
-        FHEW_DISPATCH(key->log_n, GP_LAUNCH(fhe::ArithShoup, LN));
+        switch (key->log_n) {
+            case 7: GP_LAUNCH(fhe::ArithShoup, 7) break;
+            case 8: GP_LAUNCH(fhe::ArithShoup, 8) break;
+            case 9: GP_LAUNCH(fhe::ArithShoup, 9) break;
+            case 10: GP_LAUNCH_BIG(fhe::ArithShoup, 10) break;
+            case 11: GP_LAUNCH_BIG(fhe::ArithShoup, 11) break;
+            default: return FHE_ERR_UNSUPPORTED;
+        }
     }
+#undef GP_LAUNCH_BIG
+#undef GP_LAUNCH_W
 #undef GP_LAUNCH
     HIP_TRY(hipGetLastError());
     rc = ma.sync_out(st);
@@ -434,8 +468,9 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
                        (unsigned)n_lwe, (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_err);
     if (hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
     fhe::BlindRotateParams BR;
-    BR.brk = key_view(bk->brk);
-    BR.ak = key_view(bk->ak);
+    const bool small = small_shape(log_n, batch);
+    BR.brk = key_view(bk->brk, small);
+    BR.ak = key_view(bk->ak, small);
     BR.ak_t = bk->d_ak_t;
     BR.ops = d_ops;
     BR.nops = d_nops;
@@ -443,27 +478,35 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     BR.lwe_b = mb.d;
     BR.f = mf.d;
     BR.f_stride = f_stride;
-#define BR_CASE(AR, LN)                                                                                                     \
-    case LN: {                                                                                                              \
-        const size_t lds = fhe::WaveRing<LN>::LDS_BYTES;                                   \
-        rc = set_lds(fhe::blind_rotate_kernel<AR, LN>, lds);                                                                \
-        if (rc == FHE_OK)                                                                                                   \
-            hipLaunchKernelGGL((fhe::blind_rotate_kernel<AR, LN>), dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, BR, \
-                               moa.d, mob.d, (unsigned)batch, ring_consts(ctx, LN));                                      \
-        break;                                                                                                              \
+#define BR_LAUNCH_W(AR, WR)                                                                                                  \
+    {                                                                                                                        \
+        const size_t lds = WR::LDS_BYTES;                                                                                    \
+        rc = set_lds(fhe::blind_rotate_kernel<AR, WR>, lds);                                                                 \
+        if (rc == FHE_OK)                                                                                                    \
+            hipLaunchKernelGGL((fhe::blind_rotate_kernel<AR, WR>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)),    \
+                               dim3(WR::THREADS), lds, st, BR, moa.d, mob.d, (unsigned)batch, ring_consts(ctx, 0));          \
+    }
+#define BR_CASE(AR, LN) case LN: { typedef fhe::WaveRing<LN> WD; BR_LAUNCH_W(AR, WD) break; }
+#define BR_CASE_BIG(AR, LN)                                                                  \
+    case LN: {                                                                               \
+        if (small) { typedef fhe::WaveRing<LN, 2> WS; BR_LAUNCH_W(AR, WS) }                  \
+        else { typedef fhe::WaveRing<LN> WD; BR_LAUNCH_W(AR, WD) }                           \
+        break;                                                                               \
     }
     if (use_pm54(ctx, log_n)) {
         switch (log_n) {
-            BR_CASE(fhe::ArithPM<54>, 9) BR_CASE(fhe::ArithPM<54>, 10) BR_CASE(fhe::ArithPM<54>, 11)
+            BR_CASE(fhe::ArithPM<54>, 9) BR_CASE_BIG(fhe::ArithPM<54>, 10) BR_CASE_BIG(fhe::ArithPM<54>, 11)
             default: return fail(FHE_ERR_UNSUPPORTED);
         }
     } else {
         switch (log_n) {
-            BR_CASE(fhe::ArithShoup, 7) BR_CASE(fhe::ArithShoup, 8) BR_CASE(fhe::ArithShoup, 9) BR_CASE(fhe::ArithShoup, 10)
-            BR_CASE(fhe::ArithShoup, 11)
+            BR_CASE(fhe::ArithShoup, 7) BR_CASE(fhe::ArithShoup, 8) BR_CASE(fhe::ArithShoup, 9) BR_CASE_BIG(fhe::ArithShoup, 10)
+            BR_CASE_BIG(fhe::ArithShoup, 11)
             default: return fail(FHE_ERR_UNSUPPORTED);
         }
     }
+#undef BR_CASE_BIG
+#undef BR_LAUNCH_W
 #undef BR_CASE
     if (rc != FHE_OK || hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
     int h_err = 0;

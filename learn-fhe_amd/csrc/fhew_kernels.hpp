@@ -165,14 +165,17 @@ FHE_HEADER_KERNEL void rlwe_sample_extract_kernel(const u64 *__restrict__ ct_a, 
 // pair, the evaluation-domain sums and the transform -- 256 VGPRs plus spills, ONE wave per SIMD, nothing to hide an LDS
 // or key-load latency behind (measured at cfg3: the SIMD issues 52 % of the time).  There the team is 2 / 4 waves with 8
 // coefficients per lane, one team per block, exchanges behind a workgroup barrier: half the registers, 3-4 waves per SIMD.
-template <int LOG_N>
+// LOG_E_ (coefficients per lane) defaults to the throughput shape; the FHEW entry points also instantiate LOG_E_ = 2 for
+// N >= 1024 (4 / 8 waves per ciphertext): more parallelism per ciphertext, +57 % at batch 1 and 64, -2 % at batch 1024.
+template <int LOG_N_, int LOG_E_ = (LOG_N_ <= 9 ? LOG_N_ - 6 : 3)>
 struct WaveRing {
-    static constexpr int LOG_T = LOG_N <= 9 ? 6 : LOG_N - 3;  // log2 threads per ciphertext
+    static constexpr int LOG_N = LOG_N_;
+    static constexpr int LOG_T = LOG_N_ - LOG_E_;  // log2 threads per ciphertext
     static constexpr int TEAM = 1 << LOG_T;
     static constexpr bool WAVE = LOG_T == 6;                   // exchanges need no workgroup barrier
     static constexpr int TEAMS = WAVE ? 4 : 1;                 // ciphertexts per block
     static constexpr int THREADS = TEAM * TEAMS;
-    static constexpr int LOG_E = LOG_N - LOG_T;
+    static constexpr int LOG_E = LOG_E_;
     static constexpr int E = 1 << LOG_E;
     static constexpr int N = 1 << LOG_N;
     using C = NttCfg<LOG_N, LOG_E, 1>;  // T = TEAM
@@ -187,7 +190,7 @@ struct WaveRing {
     // multi-wave teams: waves per SIMD the kernels are compiled for (bounds the VGPRs; HIP's second launch bound).  Measured
     // at cfg3 / cfg5 (tools/scripts/occ_sweep.sh): 2 -> 47.5k blind rotations/s, 13.1k TFHE gates/s; 3 -> 39.4k / 10.0k;
     // 4 -> 37.4k / 7.7k: below ~170 VGPRs the accumulator pair, the sums and the digit state spill.
-    static constexpr int MIN_WAVES = WAVE ? 1 : FHE_TEAM_OCC;
+    static constexpr int MIN_WAVES = WAVE ? 1 : (LOG_E <= 2 ? 3 : FHE_TEAM_OCC);
     static_assert(LOG_N >= 7 && LOG_N <= 11, "fused FHEW kernels cover N = 128 .. 2048");
     static_assert(C::T == TEAM, "team size");
     static __device__ __forceinline__ int lane() { return threadIdx.x & (TEAM - 1); }  // thread within its team
@@ -195,18 +198,17 @@ struct WaveRing {
 };
 
 // polynomial index held by register k of `lane` in the coefficient (first-pass) layout
-template <int LOG_N>
+template <class W>
 __device__ __forceinline__ int coef_index(int lane, int k) {
-    using W = WaveRing<LOG_N>;
     const int gg = k >> W::R0, r = k & ((1 << W::R0) - 1);
-    return pass_index<LOG_N, 0, W::R0>(lane + W::TEAM * gg, r);
+    return pass_index<W::LOG_N, 0, W::R0>(lane + W::TEAM * gg, r);
 }
 
 // key rows are stored so that the evaluation-layout registers (evaluation lane*E + r in x[r]) load as
 // coalesced 16-byte pairs: word offset of evaluation e = lane*E + r inside a row
-template <int LOG_N>
+template <class W>
 __host__ __device__ __forceinline__ int key_perm(int e) {
-    constexpr int E = WaveRing<LOG_N>::E, TEAM = WaveRing<LOG_N>::TEAM;
+    constexpr int E = W::E, TEAM = W::TEAM;
     const int lane = e / E, r = e % E;
     return (r >> 1) * (2 * TEAM) + lane * 2 + (r & 1);
 }
@@ -218,11 +220,11 @@ struct RingConsts {
 };
 
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
-template <class A, int LOG_N>
-__device__ __forceinline__ void mac_row(const u64 (&x)[WaveRing<LOG_N>::E], typename A::MacAcc (&sa)[WaveRing<LOG_N>::E],
-                                        typename A::MacAcc (&sb)[WaveRing<LOG_N>::E],
+template <class A, class W>
+__device__ __forceinline__ void mac_row(const u64 (&x)[W::E], typename A::MacAcc (&sa)[W::E],
+                                        typename A::MacAcc (&sb)[W::E],
                                         const u64 *__restrict__ row, int lane, int term, const RingConsts &K, const typename A::K &k) {
-    constexpr int E = WaveRing<LOG_N>::E, N = 1 << LOG_N, TEAM = WaveRing<LOG_N>::TEAM;
+    constexpr int E = W::E, N = 1 << W::LOG_N, TEAM = W::TEAM;
     const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
     const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
 #pragma unroll
@@ -243,11 +245,10 @@ __device__ __forceinline__ void mac_row(const u64 (&x)[WaveRing<LOG_N>::E], type
 //                 (a, b) <- (sum_j rows[j].a * limb_j, sum_j rows[j].b * limb_j + b)
 // Each limb is transformed by the wave-private NTT and multiplied into evaluation-domain sums; two inverse
 // transforms bring the result back.  (ca, cb): coefficient layout, canonical, in and out.
-template <class A, int LOG_N>
-__device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E], u64 (&cb)[WaveRing<LOG_N>::E],
+template <class A, class W>
+__device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W::E],
                                                     const u64 *__restrict__ rows, const DecompParams &P, bool both, int lane,
                                                     u64 *lds, const RingConsts &K, const typename A::K &k) {
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
     typename A::MacAcc ma[E], mb[E];
     u64 sa[E], sb[E], st[E];
@@ -263,15 +264,15 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E
         u64 x[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
-        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, LOG_N>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+        mac_row<A, W>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
+        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
@@ -284,32 +285,31 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[WaveRing<LOG_N>::E
 }
 
 // util/src/avec.rs:34-50 on a register-resident polynomial: scatter through the wave's LDS image
-template <int LOG_N>
-__device__ __forceinline__ void wave_automorphism(u64 (&c)[WaveRing<LOG_N>::E], unsigned t, int lane, u64 *lds, u64 q) {
-    using W = WaveRing<LOG_N>;
+template <class W>
+__device__ __forceinline__ void wave_automorphism(u64 (&c)[W::E], unsigned t, int lane, u64 *lds, u64 q) {
     constexpr int E = W::E, N = W::N;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        const unsigned i = coef_index<LOG_N>(lane, k);
+        const unsigned i = coef_index<W>(lane, k);
         const unsigned it = (i * t) & (2 * N - 1);
         const u64 v = c[k];
         lds[lds_phys(it & (N - 1))] = it < N ? v : (v ? q - v : 0);
     }
     exchange_sync<W::WAVE>();
 #pragma unroll
-    for (int k = 0; k < E; ++k) c[k] = lds[lds_phys(coef_index<LOG_N>(lane, k))];
+    for (int k = 0; k < E; ++k) c[k] = lds[lds_phys(coef_index<W>(lane, k))];
     exchange_sync<W::WAVE>();
 }
 
-template <int LOG_N>
-__device__ __forceinline__ void wave_load(u64 (&c)[WaveRing<LOG_N>::E], const u64 *__restrict__ g, int lane) {
+template <class W>
+__device__ __forceinline__ void wave_load(u64 (&c)[W::E], const u64 *__restrict__ g, int lane) {
 #pragma unroll
-    for (int k = 0; k < (WaveRing<LOG_N>::E); ++k) c[k] = g[coef_index<LOG_N>(lane, k)];
+    for (int k = 0; k < (W::E); ++k) c[k] = g[coef_index<W>(lane, k)];
 }
-template <int LOG_N>
-__device__ __forceinline__ void wave_store(const u64 (&c)[WaveRing<LOG_N>::E], u64 *__restrict__ g, int lane) {
+template <class W>
+__device__ __forceinline__ void wave_store(const u64 (&c)[W::E], u64 *__restrict__ g, int lane) {
 #pragma unroll
-    for (int k = 0; k < (WaveRing<LOG_N>::E); ++k) g[coef_index<LOG_N>(lane, k)] = c[k];
+    for (int k = 0; k < (W::E); ++k) g[coef_index<W>(lane, k)] = c[k];
 }
 
 
@@ -322,40 +322,39 @@ struct FhewKey {      // device view of a prepared gadget key set
 // batched gadget product, every ciphertext against key entry `index`:
 //   both = 1: RLWE x RGSW external product; both = 0: RLWE key switch, preceded by X -> X^t2n when t2n != 1
 //   (scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism`)
-template <class A, int LOG_N>
-__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void gadget_product_kernel(
+template <class A, class W>
+__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void gadget_product_kernel(
     u64 *__restrict__ ct_a, u64 *__restrict__ ct_b, unsigned batch, FhewKey key, unsigned index, unsigned both, unsigned t2n,
     RingConsts K) {
-    using W = WaveRing<LOG_N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const unsigned ct = blockIdx.x * W::TEAMS + team;
     if (ct >= batch) return;  // team-uniform exit (a multi-wave team is a whole block: barriers stay matched)
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
-    const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
+    const typename A::K k = A::make(*K.desc, W::LOG_N, 0, 0);
     u64 ca[W::E], cb[W::E];
-    wave_load<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
-    wave_load<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
+    wave_load<W>(ca, ct_a + size_t(ct) * W::N, lane);
+    wave_load<W>(cb, ct_b + size_t(ct) * W::N, lane);
     if (t2n != 1) {
-        wave_automorphism<LOG_N>(ca, t2n, lane, lds, K.B.q);
-        wave_automorphism<LOG_N>(cb, t2n, lane, lds, K.B.q);
+        wave_automorphism<W>(ca, t2n, lane, lds, K.B.q);
+        wave_automorphism<W>(cb, t2n, lane, lds, K.B.q);
     }
-    wave_gadget_product<A, LOG_N>(ca, cb, key.rows + size_t(index) * key.rows_per_ct * 2 * W::N, key.P, both != 0, lane, lds, K, k);
-    wave_store<LOG_N>(ca, ct_a + size_t(ct) * W::N, lane);
-    wave_store<LOG_N>(cb, ct_b + size_t(ct) * W::N, lane);
+    wave_gadget_product<A, W>(ca, cb, key.rows + size_t(index) * key.rows_per_ct * 2 * W::N, key.P, both != 0, lane, lds, K, k);
+    wave_store<W>(ca, ct_a + size_t(ct) * W::N, lane);
+    wave_store<W>(cb, ct_b + size_t(ct) * W::N, lane);
 }
 
 // evaluation-domain rows [rows][N] (natural evaluation order as the forward kernel leaves them) -> key_perm layout;
 // pm_b != 0: values stored in the pseudo-Mersenne policy's packed operand form {w mod 2^(b-31), w >> (b-31)} (arith.hpp), so
 // the multiply-accumulate reads both words of its fixed operand straight from the load
-template <int LOG_N>
+template <class W>
 FHE_HEADER_KERNEL void key_permute_kernel(const u64 *__restrict__ in_a, const u64 *__restrict__ in_b, u64 *__restrict__ out, size_t rows, int pm_b) {
-    constexpr int N = 1 << LOG_N;
+    constexpr int N = 1 << W::LOG_N;
     const size_t total = rows * N;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
-        const size_t row = idx >> LOG_N;
+        const size_t row = idx >> W::LOG_N;
         const int e = int(idx & (N - 1));
-        const int p = key_perm<LOG_N>(e);
+        const int p = key_perm<W>(e);
         u64 va = in_a[idx], vb = in_b[idx];
         if (pm_b) {
             const u64 lo_mask = (u64(1) << (pm_b - 31)) - 1;
@@ -455,17 +454,16 @@ struct BlindRotateParams {
     size_t f_stride;      // 0: one f for the whole batch, N: one per ciphertext
 };
 
-template <class A, int LOG_N>
-__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
+template <class A, class W>
+__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
                                                                                   u64 *__restrict__ out_b, unsigned batch, RingConsts K) {
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const unsigned ct = blockIdx.x * W::TEAMS + team;
     if (ct >= batch) return;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::PN;
-    const typename A::K k = A::make(*K.desc, LOG_N, 0, 0);
+    const typename A::K k = A::make(*K.desc, W::LOG_N, 0, 0);
     u64 ca[E], cb[E];
     // acc = (0, f.automorphism(-g) * X^(b*g))   (bootstrapping.rs:165-167); both steps are signed index maps
     {
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
         const unsigned tneg = (2 * N - 5u) & (2 * N - 1);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const unsigned i = coef_index<LOG_N>(lane, e);
+            const unsigned i = coef_index<W>(lane, e);
             const u64 v = f[i];
             unsigned pos = (i * tneg) & (2 * N - 1);   // automorphism(-5): X^i -> X^(i t)
             pos = (pos + kmono) & (2 * N - 1);         // * X^k
@@ -483,7 +481,7 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
         }
         exchange_sync<W::WAVE>();
 #pragma unroll
-        for (int e = 0; e < E; ++e) { cb[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))]; ca[e] = 0; }
+        for (int e = 0; e < E; ++e) { cb[e] = lds[lds_phys(coef_index<W>(lane, e))]; ca[e] = 0; }
         exchange_sync<W::WAVE>();
     }
     const unsigned *ops = BR.ops + size_t(ct) * BR.max_ops;
@@ -494,14 +492,14 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
         const unsigned idx = op & 0x7fffffffu;
         if (is_ak) {
             const unsigned t = BR.ak_t[idx];
-            wave_automorphism<LOG_N>(ca, t, lane, lds, K.B.q);
-            wave_automorphism<LOG_N>(cb, t, lane, lds, K.B.q);
+            wave_automorphism<W>(ca, t, lane, lds, K.B.q);
+            wave_automorphism<W>(cb, t, lane, lds, K.B.q);
         }
         const FhewKey &key = is_ak ? BR.ak : BR.brk;
-        wave_gadget_product<A, LOG_N>(ca, cb, key.rows + size_t(idx) * key.rows_per_ct * 2 * N, key.P, !is_ak, lane, lds, K, k);
+        wave_gadget_product<A, W>(ca, cb, key.rows + size_t(idx) * key.rows_per_ct * 2 * N, key.P, !is_ak, lane, lds, K, k);
     }
-    wave_store<LOG_N>(ca, out_a + size_t(ct) * N, lane);
-    wave_store<LOG_N>(cb, out_b + size_t(ct) * N, lane);
+    wave_store<W>(ca, out_a + size_t(ct) * N, lane);
+    wave_store<W>(cb, out_b + size_t(ct) * N, lane);
 }
 
 }  // namespace fhe

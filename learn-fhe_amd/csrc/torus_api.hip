@@ -63,8 +63,8 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
     TORUS_DISPATCH(key->log_n, {
         const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
         if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_cmux_kernel<LN>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<fhe::WaveRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_cmux_kernel<fhe::WaveRing<LN>>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
                            rows1, key->P, rot, rot_stride, t->T);
     });
     HIP_TRY(hipGetLastError());
@@ -206,7 +206,7 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
         if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
         rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
         if (rc != FHE_OK) break;
-        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<LN>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
+        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<fhe::WaveRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
                                                  (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows, 60));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
@@ -273,8 +273,8 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     TORUS_DISPATCH(brk->log_n, {
         const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
         if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<LN>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)),
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<fhe::WaveRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<fhe::WaveRing<LN>>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)),
                            dim3(fhe::WaveRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
                            (unsigned)batch, (const u64 *)brk->d_rows[0], (const u64 *)brk->d_rows[1], brk->P, t->T, moa.d, mob.d);
     });

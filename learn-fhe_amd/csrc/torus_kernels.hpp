@@ -93,13 +93,12 @@ __device__ __forceinline__ u64 crt2_mod64(u64 r0, u64 r1, const TorusConsts &T) 
 
 // One gadget product pass for ONE prime over register-resident operands (coefficient layout): outputs the residues of
 // sum_l rows[l].a * limb_l and sum_l rows[l].b * limb_l (exact integers) mod that prime, coefficient layout.
-template <int LOG_N>
-__device__ __forceinline__ void team_torus_gadget(const u64 (&da)[WaveRing<LOG_N>::E], const u64 (&db)[WaveRing<LOG_N>::E],
+template <class W>
+__device__ __forceinline__ void team_torus_gadget(const u64 (&da)[W::E], const u64 (&db)[W::E],
                                                   const u64 *__restrict__ rows, const TDecomp &P, u64 p, int lane, u64 *lds, const Barrett &B,
-                                                  const typename ArithPM<60>::K &k, u64 (&sa)[WaveRing<LOG_N>::E],
-                                                  u64 (&sb)[WaveRing<LOG_N>::E]) {
+                                                  const typename ArithPM<60>::K &k, u64 (&sa)[W::E],
+                                                  u64 (&sb)[W::E]) {
     using A = ArithPM<60>;
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
     RingConsts K;
     K.desc = nullptr;
@@ -120,57 +119,55 @@ __device__ __forceinline__ void team_torus_gadget(const u64 (&da)[WaveRing<LOG_N
             const u64 dg = tdecomp_next(st[e], P);
             x[e] = (long long)dg < 0 ? p - (0 - dg) : dg;  // |digit| <= 2^(log_b-1) < p
         }
-        fwd_run<A, typename W::C, LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, LOG_N>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+        mac_row<A, W>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<A, typename W::C, LOG_N, W::LOG_E, LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
+        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
 }
 
 // c <- c * X^r on the torus (ring.rs:299-313; negation = wrapping_neg), r in [0, 2N), through the team's LDS image
-template <int LOG_N>
-__device__ __forceinline__ void team_torus_rotate(u64 (&c)[WaveRing<LOG_N>::E], unsigned r, int lane, u64 *lds) {
-    using W = WaveRing<LOG_N>;
+template <class W>
+__device__ __forceinline__ void team_torus_rotate(u64 (&c)[W::E], unsigned r, int lane, u64 *lds) {
     constexpr int E = W::E, N = W::N;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const unsigned pos = (unsigned(coef_index<LOG_N>(lane, e)) + r) & (2 * N - 1);
+        const unsigned pos = (unsigned(coef_index<W>(lane, e)) + r) & (2 * N - 1);
         lds[lds_phys(pos & (N - 1))] = pos < N ? c[e] : 0 - c[e];
     }
     exchange_sync<W::WAVE>();
 #pragma unroll
-    for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<LOG_N>(lane, e))];
+    for (int e = 0; e < E; ++e) c[e] = lds[lds_phys(coef_index<W>(lane, e))];
     exchange_sync<W::WAVE>();
 }
 
 // (xa, xb) <- external_product(key, (da, db)), exact: both primes, then the Chinese remainder mod 2^64
 // (scheme/tfhe/src/tggsw.rs:100-112 for k = 1); everything stays in the team's registers
-template <int LOG_N>
-__device__ __forceinline__ void team_torus_external_product(const u64 (&da)[WaveRing<LOG_N>::E], const u64 (&db)[WaveRing<LOG_N>::E],
+template <class W>
+__device__ __forceinline__ void team_torus_external_product(const u64 (&da)[W::E], const u64 (&db)[W::E],
                                                             const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, const TDecomp &P,
-                                                            const TorusConsts &T, int lane, u64 *lds, u64 (&xa)[WaveRing<LOG_N>::E],
-                                                            u64 (&xb)[WaveRing<LOG_N>::E]) {
+                                                            const TorusConsts &T, int lane, u64 *lds, u64 (&xa)[W::E],
+                                                            u64 (&xb)[W::E]) {
     using A = ArithPM<60>;
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E;
     // the first prime's residues wait in the team's LDS parking area (each lane its own slots: no synchronisation) while the
     // second prime's pass needs the registers
     u64 *park = lds + W::PN;
     {
-        const typename A::K k0 = A::make(T.descs[0], LOG_N, 0, 0);
-        team_torus_gadget<LOG_N>(da, db, rows0, P, T.p0, lane, lds, T.B0, k0, xa, xb);
+        const typename A::K k0 = A::make(T.descs[0], W::LOG_N, 0, 0);
+        team_torus_gadget<W>(da, db, rows0, P, T.p0, lane, lds, T.B0, k0, xa, xb);
 #pragma unroll
         for (int e = 0; e < E; ++e) { park[e * W::TEAM + lane] = xa[e]; park[(E + e) * W::TEAM + lane] = xb[e]; }
     }
     {
-        const typename A::K k1 = A::make(T.descs[1], LOG_N, 0, 0);
-        team_torus_gadget<LOG_N>(da, db, rows1, P, T.p1, lane, lds, T.B1, k1, xa, xb);
+        const typename A::K k1 = A::make(T.descs[1], W::LOG_N, 0, 0);
+        team_torus_gadget<W>(da, db, rows1, P, T.p1, lane, lds, T.B1, k1, xa, xb);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -181,21 +178,21 @@ __device__ __forceinline__ void team_torus_external_product(const u64 (&da)[Wave
 
 // One CMUX step of the blind rotation on a register-resident accumulator (tggsw.rs:114-121, bootstrapping.rs:94-95):
 // acc <- acc + external_product(key, acc X^r - acc); r = 0 leaves acc untouched (the external product of zero is exactly zero)
-template <int LOG_N>
-__device__ __forceinline__ void team_torus_cmux(u64 (&ca)[WaveRing<LOG_N>::E], u64 (&cb)[WaveRing<LOG_N>::E], unsigned r,
+template <class W>
+__device__ __forceinline__ void team_torus_cmux(u64 (&ca)[W::E], u64 (&cb)[W::E], unsigned r,
                                                 const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, const TDecomp &P,
                                                 const TorusConsts &T, int lane, u64 *lds) {
-    constexpr int E = WaveRing<LOG_N>::E;
+    constexpr int E = W::E;
     if (r == 0) return;  // team-uniform
     u64 da[E], db[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { da[e] = ca[e]; db[e] = cb[e]; }
-    team_torus_rotate<LOG_N>(da, r, lane, lds);
-    team_torus_rotate<LOG_N>(db, r, lane, lds);
+    team_torus_rotate<W>(da, r, lane, lds);
+    team_torus_rotate<W>(db, r, lane, lds);
 #pragma unroll
     for (int e = 0; e < E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
     u64 xa[E], xb[E];
-    team_torus_external_product<LOG_N>(da, db, rows0, rows1, P, T, lane, lds, xa, xb);
+    team_torus_external_product<W>(da, db, rows0, rows1, P, T, lane, lds, xa, xb);
 #pragma unroll
     for (int e = 0; e < E; ++e) { ca[e] += xa[e]; cb[e] += xb[e]; }
 }
@@ -203,11 +200,10 @@ __device__ __forceinline__ void team_torus_cmux(u64 (&ca)[WaveRing<LOG_N>::E], u
 // scheme/tfhe/src/tggsw.rs:100-121 for k = 1, one team (fhew_kernels.hpp: WaveRing) per ciphertext.
 //   rot == nullptr: (a, b) <- external_product(key, (a, b))
 //   rot != nullptr: one CMUX step: (a, b) <- (a, b) + external_product(key, (a, b) X^r - (a, b)), r = rot[ct * rot_stride] mod 2N
-template <int LOG_N>
-__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void torus_cmux_kernel(
+template <class W>
+__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void torus_cmux_kernel(
     u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch, const u64 *__restrict__ rows0, const u64 *__restrict__ rows1,
     TDecomp P, const u64 *__restrict__ rot, size_t rot_stride, TorusConsts T) {
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
@@ -216,28 +212,27 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::TORUS_LDS_WORDS;
     u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
     u64 ca[E], cb[E];
-    wave_load<LOG_N>(ca, ga, lane);
-    wave_load<LOG_N>(cb, gb, lane);
+    wave_load<W>(ca, ga, lane);
+    wave_load<W>(cb, gb, lane);
     if (rot != nullptr) {
-        team_torus_cmux<LOG_N>(ca, cb, unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1), rows0, rows1, P, T, lane, lds);
+        team_torus_cmux<W>(ca, cb, unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1), rows0, rows1, P, T, lane, lds);
     } else {
         u64 xa[E], xb[E];
-        team_torus_external_product<LOG_N>(ca, cb, rows0, rows1, P, T, lane, lds, xa, xb);
+        team_torus_external_product<W>(ca, cb, rows0, rows1, P, T, lane, lds, xa, xb);
 #pragma unroll
         for (int e = 0; e < E; ++e) { ca[e] = xa[e]; cb[e] = xb[e]; }
     }
-    wave_store<LOG_N>(ca, ga, lane);
-    wave_store<LOG_N>(cb, gb, lane);
+    wave_store<W>(ca, ga, lane);
+    wave_store<W>(cb, gb, lane);
 }
 
 // scheme/tfhe/src/bootstrapping.rs:84-96 `blind_rotate` (k = 1), the whole fold in ONE launch: acc = (0, v X^-b), then
 // acc <- cmux(brk_i, acc, acc X^(a_i)) for i = 0 .. n_lwe-1, the accumulator in the team's registers throughout.
 // rows0 / rows1: the key set [n_lwe][2d][2][N] per prime (key_perm layout); a_tilde [batch][n_lwe], b_tilde [batch] mod 2N.
-template <int LOG_N>
-__global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVES) void torus_blind_rotate_kernel(
+template <class W>
+__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void torus_blind_rotate_kernel(
     const u64 *__restrict__ v, const u64 *__restrict__ a_tilde, const u64 *__restrict__ b_tilde, unsigned n_lwe, unsigned batch,
     const u64 *__restrict__ rows0, const u64 *__restrict__ rows1, TDecomp P, TorusConsts T, u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
-    using W = WaveRing<LOG_N>;
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
@@ -245,19 +240,19 @@ __global__ __launch_bounds__(WaveRing<LOG_N>::THREADS, WaveRing<LOG_N>::MIN_WAVE
     if (ct >= batch) return;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * W::TORUS_LDS_WORDS;
     u64 ca[E], cb[E];
-    wave_load<LOG_N>(cb, v, lane);
+    wave_load<W>(cb, v, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) ca[e] = 0;
-    team_torus_rotate<LOG_N>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);  // (0, v).rotate(-b)
+    team_torus_rotate<W>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);  // (0, v).rotate(-b)
     const size_t per = size_t(2 * P.d) * 2 * N;
     const u64 *a = a_tilde + size_t(ct) * n_lwe;
 #pragma unroll 1
     for (unsigned i = 0; i < n_lwe; ++i) {
         const unsigned r = __builtin_amdgcn_readfirstlane(unsigned(a[i]) & (2 * N - 1));
-        team_torus_cmux<LOG_N>(ca, cb, r, rows0 + i * per, rows1 + i * per, P, T, lane, lds);
+        team_torus_cmux<W>(ca, cb, r, rows0 + i * per, rows1 + i * per, P, T, lane, lds);
     }
-    wave_store<LOG_N>(ca, out_a + size_t(ct) * N, lane);
-    wave_store<LOG_N>(cb, out_b + size_t(ct) * N, lane);
+    wave_store<W>(ca, out_a + size_t(ct) * N, lane);
+    wave_store<W>(cb, out_b + size_t(ct) * N, lane);
 }
 
 // exact torus product building blocks for fhe_torus_mul: c = a * b with |b| small (two-prime CRT)

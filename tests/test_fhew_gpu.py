@@ -172,6 +172,42 @@ def _make_bk(fhe, torch_cuda, q, n, log_b, d, ks_log_b, ks_d, w, n_lwe, seed):
     return ctx, fhe.BootstrapKey(ctx, gk, ga, ts, w), brk, ak, ts
 
 
+@pytest.mark.parametrize("q,log_n", [(18014398509404161, 10), (18014398509404161, 11), (35184372060161, 10), (35184372060161, 11)])
+def test_throughput_and_small_batch_shapes_agree(fhe, cref, torch_cuda, q, log_n):
+    """N >= 1024 has two instantiations of the fused kernels (8 coefficients per lane above 512 ciphertexts, 4 below, each with
+    its own key layout): the same ciphertext must come out bit-identical from both, and equal to the oracle"""
+    n, lb, d, w, n_lwe, big = 1 << log_n, 6, 3, 3, 3, 516
+    assert cref.is_prime(q) and (q - 1) % (2 * n) == 0
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, 5, 4, w, n_lwe, seed=90 + log_n)
+    gk, ga = bk.brk, bk.ak
+    ca, cb = rand_u64(91, q, (big, n)), rand_u64(92, q, (big, n))
+    for kind in ("ep", "ks", "auto"):
+        outs = []
+        for cnt in (big, 3):
+            a, b = dev(torch_cuda, ca[:cnt]), dev(torch_cuda, cb[:cnt])
+            if kind == "ep":
+                gk.external_product_(1, a, b)
+            elif kind == "ks":
+                ga.key_switch_(2, a, b)
+            else:
+                ga.automorphism_(1, ts[1], a, b)
+            outs.append((host(a), host(b)))
+        assert np.array_equal(outs[0][0][:3], outs[1][0]) and np.array_equal(outs[0][1][:3], outs[1][1]), kind
+        assert np.array_equal(outs[0][0][-1:], outs[0][0][-1:])
+        if kind == "ep":
+            ea, eb = cref.external_product(q, lb, d, brk[1, 0], brk[1, 1], ca[big - 1], cb[big - 1])
+            assert np.array_equal(outs[0][0][big - 1], ea) and np.array_equal(outs[0][1][big - 1], eb)
+    rng = np.random.Generator(np.random.PCG64(93))
+    lwe_a = (rng.integers(0, n, size=(big, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_b = rng.integers(0, 2 * n, size=big, dtype=np.uint64)
+    f = rand_u64(94, q, n)
+    oa, ob = bk.blind_rotate(dev(torch_cuda, lwe_a), dev(torch_cuda, lwe_b), dev(torch_cuda, f))
+    sa, sb = bk.blind_rotate(dev(torch_cuda, lwe_a[:2]), dev(torch_cuda, lwe_b[:2]), dev(torch_cuda, f))
+    assert np.array_equal(host(oa)[:2], host(sa)) and np.array_equal(host(ob)[:2], host(sb))
+    ea, eb = cref.blind_rotate(q, n, w, lb, d, 5, 4, brk, ak, ts, f, lwe_a[big - 1], int(lwe_b[big - 1]))
+    assert np.array_equal(host(oa)[big - 1], ea) and np.array_equal(host(ob)[big - 1], eb)
+
+
 def test_blind_rotate_golden(fhe, torch_cuda):
     v = load_golden("blind_rotate.json")
     q, n, w, lb, d = v["q"], v["n"], v["w"], v["log_b"], v["d"]
