@@ -46,6 +46,15 @@ inline unsigned grid_for(size_t total) {
     return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
 }
 
+// the team shape of the torus kernels per ring degree: 4 coefficients per lane from N = 1024 up (the state of a CMUX -- accumulator,
+// difference, digit state, two unreduced sum pairs -- is heavier than FHEW's; measured at cfg5: 17.2-17.3 k gates/s against
+// 16.6-16.9 k with 8 per lane, same session, and the better shape for small batches as well)
+#ifndef FHE_TORUS_LOG_E
+#define FHE_TORUS_LOG_E 2
+#endif
+template <int LN>
+using TorusRing = fhe::WaveRing<LN, (LN <= 9 ? LN - 6 : FHE_TORUS_LOG_E)>;
+
 #define TORUS_DISPATCH(log_n, ...)                                         \
     switch (log_n) {                                                       \
         case 8: { constexpr int LN = 8; __VA_ARGS__; break; }              \
@@ -61,10 +70,10 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
     const size_t per = size_t(2 * key->d) * 2 * n;
     const u64 *rows0 = key->d_rows[0] + index * per, *rows1 = key->d_rows[1] + index * per;
     TORUS_DISPATCH(key->log_n, {
-        const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
+        const size_t lds = TorusRing<LN>::TORUS_LDS_BYTES;
         if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<fhe::WaveRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_cmux_kernel<fhe::WaveRing<LN>>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)), dim3(fhe::WaveRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_cmux_kernel<TorusRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_cmux_kernel<TorusRing<LN>>, dim3((unsigned)((batch + TorusRing<LN>::TEAMS - 1) / TorusRing<LN>::TEAMS)), dim3(TorusRing<LN>::THREADS), lds, st, a, b, (unsigned)batch, rows0,
                            rows1, key->P, rot, rot_stride, t->T);
     });
     HIP_TRY(hipGetLastError());
@@ -206,7 +215,7 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
         if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
         rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
         if (rc != FHE_OK) break;
-        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<fhe::WaveRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
+        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<TorusRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
                                                  (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows, 60));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
@@ -271,11 +280,11 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     // accumulator never leaves the registers of the team that owns the ciphertext
     int rc = FHE_OK;
     TORUS_DISPATCH(brk->log_n, {
-        const size_t lds = fhe::WaveRing<LN>::TORUS_LDS_BYTES;
+        const size_t lds = TorusRing<LN>::TORUS_LDS_BYTES;
         if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<fhe::WaveRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<fhe::WaveRing<LN>>, dim3((unsigned)((batch + fhe::WaveRing<LN>::TEAMS - 1) / fhe::WaveRing<LN>::TEAMS)),
-                           dim3(fhe::WaveRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
+            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<TorusRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<TorusRing<LN>>, dim3((unsigned)((batch + TorusRing<LN>::TEAMS - 1) / TorusRing<LN>::TEAMS)),
+                           dim3(TorusRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
                            (unsigned)batch, (const u64 *)brk->d_rows[0], (const u64 *)brk->d_rows[1], brk->P, t->T, moa.d, mob.d);
     });
     if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
