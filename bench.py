@@ -211,6 +211,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
+            # RCCL carries only the barriers and the max-over-ranks reduction of one scalar (no data-path collective exists)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
