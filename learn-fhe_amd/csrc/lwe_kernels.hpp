@@ -75,6 +75,48 @@ __global__ __launch_bounds__(KS_THREADS) void lwe_key_switch_tiled(const u64 *__
     }
 }
 
+// Wide-output variant (TFHE: 630 output columns, 5120 rows): the grid also splits the columns (blockIdx.y owns KS_THREADS of
+// them), a block owns 8 ciphertexts whose digits are kept as SIGNED BYTES (torus digits with log_b <= 7 lie in [-64, 64]), so a
+// key element fetched from L2 serves 8 ciphertexts and 640 blocks fill the GPU at batch 1024 (the 2-ciphertext tile above was
+// L2-bandwidth bound there: 2.3 ms per 1024, 4 % of a gate).
+template <int TILE>
+__global__ __launch_bounds__(KS_THREADS) void tlwe_key_switch_wide(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in,
+                                                                   unsigned n_out, unsigned batch, const u64 *__restrict__ ksk_a,
+                                                                   const u64 *__restrict__ ksk_b, TDecomp P, u64 *__restrict__ out_a,
+                                                                   u64 *__restrict__ out_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    signed char *dig = reinterpret_cast<signed char *>(smem_raw);  // [rows][TILE]
+    const unsigned ct0 = blockIdx.x * TILE;
+    const unsigned rows = n_in * P.d;
+    for (unsigned idx = threadIdx.x; idx < n_in * TILE; idx += KS_THREADS) {
+        const unsigned c = idx / n_in, i = idx - c * n_in;
+        const bool live = ct0 + c < batch;
+        u64 st = live ? tdecomp_init(ct_a[size_t(ct0 + c) * n_in + i], P) : 0;
+        for (int j = 0; j < P.d; ++j) dig[(size_t(j) * n_in + i) * TILE + c] = live ? (signed char)(long long)tdecomp_next(st, P) : 0;
+    }
+    __syncthreads();
+    const unsigned col = blockIdx.y * KS_THREADS + threadIdx.x;
+    if (col > n_out) return;
+    u64 acc[TILE];
+#pragma unroll
+    for (int c = 0; c < TILE; ++c) acc[c] = 0;
+    const u64 *kp = col < n_out ? ksk_a + col : ksk_b;
+    const size_t stride = col < n_out ? n_out : 1;
+#pragma unroll 4
+    for (unsigned row = 0; row < rows; ++row) {
+        const u64 kv = kp[row * stride];
+        const signed char *dr = dig + size_t(row) * TILE;
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) acc[c] += kv * (u64)(long long)dr[c];  // wrapping: arithmetic mod 2^64
+    }
+#pragma unroll
+    for (int c = 0; c < TILE; ++c) {
+        if (ct0 + c >= batch) continue;
+        if (col < n_out) out_a[size_t(ct0 + c) * n_out + col] = acc[c];
+        else out_b[ct0 + c] = acc[c] + ct_b[ct0 + c];
+    }
+}
+
 // host: ciphertexts per block for this batch and row count (LDS budget 128 KiB); 0 = digits of one ciphertext do not fit
 inline int ks_tile(size_t batch, size_t rows) {
     int tile = batch >= 2048 ? 4 : (batch >= 512 ? 2 : 1);

@@ -191,7 +191,8 @@ def test_tlwe_key_switch_tiles(fhe, torch_cuda):
     """scheme/tfhe/src/tlwe.rs:144-153 on ragged batches that take the 2- and 4-ciphertext tiles of the tiled kernel"""
     from oracle import pyref as P
     rnd = random.Random(21)
-    for log_b, d, n_in, n_out, batch in [(4, 5, 16, 5, 514), (7, 3, 8, 140, 2051)]:
+    # the last two shapes take the wide-output kernel (>= 256 columns split over the grid, 8 ciphertexts per block, byte digits)
+    for log_b, d, n_in, n_out, batch in [(4, 5, 16, 5, 514), (7, 3, 8, 140, 2051), (4, 5, 16, 300, 70), (7, 2, 32, 257, 129)]:
         dec = P.TorusDecomposor(log_b, d)
         ksa = [[rnd.getrandbits(64) for _ in range(n_out)] for _ in range(n_in * d)]
         ksb = [rnd.getrandbits(64) for _ in range(n_in * d)]
