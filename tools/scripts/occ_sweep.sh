@@ -1,5 +1,9 @@
 #!/bin/bash
-# experiment: the fused kernels compiled for 2 / 3 / 4 waves per SIMD (FHE_TEAM_OCC), secondary bench figures of each
+# experiment: the fused kernels compiled for 2 / 3 / 4 waves per SIMD (FHE_TEAM_OCC), secondary bench figures of each.
+# Build the variants first (in the build container):
+#   for occ in 2 3 4; do touch learn-fhe_amd/csrc/fhew_kernels.hpp; \
+#     make -C learn-fhe_amd/csrc -s CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DFHE_TEAM_OCC=$occ"; \
+#     cp learn-fhe_amd/lib/libfhe_ring.so tools/libfhe_occ$occ.so; done   (then rebuild the default library)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for occ in 2 3 4; do
   cp $R/tools/libfhe_occ$occ.so $R/learn-fhe_amd/lib/libfhe_ring.so
