@@ -199,3 +199,26 @@ def test_rq_elementwise_ops(fhe, torch_cuda):
         fhe.rq_scalar_mul(12289, rand_u64(4, 12289, 10), 12289)  # scalar not reduced
     with pytest.raises(fhe.FheError):
         fhe.rq_add(1 << 62, rand_u64(4, 7, 10), rand_u64(5, 7, 10))  # modulus out of range
+
+
+def test_very_large_batches(fhe, cref, torch_cuda):
+    """grid-dimension limits: hundreds of thousands of small polynomials in one call (spot-checked against the oracle), and a
+    single polynomial of the largest degree"""
+    q = cref.two_adic_primes(60, 18, 1)[0]
+    ctx = fhe.NttContext(q)
+    for n, batch in [(64, 300001), (1024, 40003), (2, 1000003)]:
+        a = rand_u64(n, q, n * batch).reshape(batch, n)
+        d = to_dev(torch_cuda, a)
+        ctx.ntt_(d, n)
+        out = to_host(d)
+        for i in (0, 1, batch // 2, batch - 2, batch - 1):
+            assert np.array_equal(out[i], cref.ntt_fwd(q, a[i], n)), (n, i)
+        ctx.intt_(d, n)
+        assert np.array_equal(to_host(d), a), n
+    n = 1 << 17
+    a = rand_u64(17, q, n)
+    d = to_dev(torch_cuda, a.reshape(1, n))
+    ctx.ntt_(d, n)
+    assert np.array_equal(to_host(d)[0], cref.ntt_fwd(q, a, n))
+    ctx.intt_(d, n)
+    assert np.array_equal(to_host(d)[0], a)
