@@ -222,3 +222,18 @@ def test_very_large_batches(fhe, cref, torch_cuda):
     assert np.array_equal(to_host(d)[0], cref.ntt_fwd(q, a, n))
     ctx.intt_(d, n)
     assert np.array_equal(to_host(d)[0], a)
+
+
+def test_c_program_through_the_abi(tmp_path, fhe):
+    """examples/c_abi_demo.c: the boundary driven from plain C (no Python, no torch in that process): BASELINE config 1's ring,
+    product against a schoolbook computed in the C program, round trip, status code for a non-prime modulus"""
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.dirname(fhe.lib_path())
+    exe = tmp_path / "c_abi_demo"
+    cmd = ["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", str(exe),
+           "-L", lib_dir, "-lfhe_ring", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c_abi_demo ok" in r.stdout, r.stdout + r.stderr
