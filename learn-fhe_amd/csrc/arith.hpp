@@ -253,8 +253,8 @@ struct ArithPM {
     // (< 2^63) is the multiplicand as it stands.  The products stay UNREDUCED: each term adds its (v, u) pair (w y = v + u 2c)
     // to a pair of 64-bit sums and ONE reduction per MAC_TERMS terms (and one in mac_finish) folds them: 6 instructions + 2
     // adds per term instead of 12 + 1.  Bounds: v < 2^(B+2); u < 2^31 y1 + 2^32 with y1 = multiplicand >> 32.
-    //  * B <= 56: multiplicands are last-pass outputs < 11 q < 2^(B+4), so u < 2^(B+3) + 2^32: 32 terms keep sum u < 2^63,
-    //    sum v < 2^62.
+    //  * B <= 56: multiplicands are forward outputs that may never have been folded (ntt_kernels.hpp: fwd_run), < (2 log2 N + 1) q
+    //    <= 27 q < 2^(B+5), so u < 2^(B+4) + 2^32: 32 terms keep sum u < 2^(B+9) + 2^37 <= 2^63 + 2^37 < 2^64, sum v < 2^(B+7).
     //  * B > 56: multiplicands < 2^63, u < 2^62 + 2^32: 3 terms keep sum u < 2^64 and sum v < 2^64 - 2^50.
     // In both cases v + u 2c < 2^(65 + bits(c)) folds to < 2^B + 2^(2 bits(c) + 6) = q + eps.
     static constexpr int MAC_TERMS = B <= 56 ? 32 : 3;
