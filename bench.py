@@ -171,14 +171,34 @@ def cpu_fhew_baseline():
     return {"blind_rotations_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg3 blind rotation"}
 
 
-def load_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), if any."""
+def load_pmc(key):
+    """A figure of the dominant kernel from the committed PMC summary (profiles/pmc_summary.json), if any."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as f:
-            return json.load(f).get("ntt_fwd_bytes_per_launch")
+            return json.load(f).get(key)
     except Exception:
         return None
+
+
+def load_traffic():
+    return load_pmc("ntt_fwd_bytes_per_launch")
+
+
+def issue_roofline(torch, dev, batch, fwd_ms):
+    """Secondary, for interpretation only (hard part 1): how close the forward kernel runs to the integer
+    ISSUE ceiling of its own instruction stream -- VALU instructions per wave (SQ_INSTS_VALU / SQ_WAVES from the committed
+    counter run) x 8 waves per polynomial, one wave-instruction per SIMD every ~4.3 cycles (4 for plain integer ops, ~4.7 for
+    v_mad_u64_u32: tools/microbench_intmul.hip), 4 SIMDs per CU at the device's maximum clock."""
+    insts = load_pmc("ntt_fwd_valu_insts_per_wave")
+    if not insts:
+        return None
+    prop = torch.cuda.get_device_properties(dev)
+    clock_hz = getattr(prop, "clock_rate", 2400000) * 1e3
+    simds = prop.multi_processor_count * 4
+    ceiling_ms = insts * 8 * batch * 4.3 / (simds * clock_hz) * 1e3
+    return {"valu_insts_per_wave": insts, "ceiling_ms_at_max_clock": ceiling_ms, "frac_of_issue_ceiling": ceiling_ms / fwd_ms,
+            "max_clock_mhz": clock_hz / 1e6, "simds": simds}
 
 
 def main():
@@ -282,7 +302,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic() if args.batch == BATCH else None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
-                         "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9},
+                         "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9,
+                         "issue": issue_roofline(torch, dev, batch, fwd_ms)},
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms

@@ -64,11 +64,20 @@ def find(kern, counter):
     return None
 
 
+def find_avg(kern, counter):
+    for k, e in summary.items():
+        if all(part in k for part in kern) and (counter + "_avg") in e:
+            return e[counter + "_avg"]
+    return None
+
+
 fw_r, fw_w = find(("ntt14_fwd_kernel<", "ArithPM<60>"), "FETCH_SIZE"), find(("ntt14_fwd_kernel<", "ArithPM<60>"), "WRITE_SIZE")
 if fw_r and fw_w:
+    insts, waves = find_avg(("ntt14_fwd_kernel<", "ArithPM<60>, false"), "SQ_INSTS_VALU"), find_avg(("ntt14_fwd_kernel<", "ArithPM<60>, false"), "SQ_WAVES")
     json.dump({"source": "profiles/%s_pmc.json" % tag, "kernel": "ntt14_fwd_kernel<ArithPM<60>> (forward, batch 4096)",
                "ntt_fwd_read_bytes_per_launch": fw_r, "ntt_fwd_write_bytes_per_launch": fw_w,
                "ntt_fwd_bytes_per_launch": fw_r + fw_w,
+               "ntt_fwd_valu_insts_per_wave": (insts / waves) if insts and waves else None,
                "correction": "FETCH_SIZE x2 (gfx950 reads 1/2, calibrated on copy8/copy16 of 512 MiB), WRITE_SIZE x1, KiB"},
               open(os.path.join("profiles", "pmc_summary.json"), "w"), indent=1)
     print("wrote profiles/pmc_summary.json", fw_r + fw_w)
