@@ -305,6 +305,9 @@ def main():
                          "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9,
                          "issue": issue_roofline(torch, dev, batch, fwd_ms)},
         }
+        prop = torch.cuda.get_device_properties(dev)
+        out["device"] = {"name": prop.name, "compute_units": prop.multi_processor_count, "max_clock_mhz": getattr(prop, "clock_rate", 0) / 1e3,
+                         "hbm_gib": round(prop.total_memory / 2 ** 30, 1), "hbm_peak_gbs_used": HBM_PEAK_GBS}
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
         if n_gpus == 1 and not args.no_fhew:
