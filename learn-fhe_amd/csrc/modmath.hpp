@@ -63,7 +63,7 @@ inline bool is_prime_u64(u64 n) {
 
 // smallest g >= 1 with g^((q-1)/2) == q-1  (util/src/zq.rs:99-105)
 inline u64 smallest_nonresidue(u64 q) {
-    for (u64 g = 1; g < q - 1; ++g)
+    for (u64 g = 1; g < q - 1; ++g)  // zq.rs:99-105: `(1..order)`, order = q - 1 excluded (q = 3 has no candidate: the reference panics)
         if (powmod(g, (q - 1) >> 1, q) == q - 1) return g;
     return 0;
 }

@@ -146,6 +146,7 @@ int ctx_build_host(uint64_t q, fhe_ctx *c) {
     c->q = q;
     c->s = __builtin_ctzll(q - 1);
     c->g = smallest_nonresidue(q);
+    if (c->g == 0) return FHE_ERR_INVALID;  // q = 3: `Zq::generator` finds nothing in 1..q-1 and unwraps None (zq.rs:99-105)
     c->omega = powmod(c->g, (q - 1) >> c->s, q);
     // the reference table has 2^(s-1) entries, entry j = omega^bitrev_{s-1}(j).  Bit-reversed tables are
     // prefix-nested, so the first 2^k entries equal psi^bitrev_k(j) with psi = omega^(2^(s-1-k)).

@@ -117,3 +117,16 @@ def test_header_is_plain_c_and_links(tmp_path, fhe):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert len(names) >= 50
+
+
+def test_tiny_moduli_follow_the_reference(fhe):
+    """util/src/zq.rs:99-105 searches the generator in 1..q-1 (exclusive): q = 3 has no candidate and the reference panics there;
+    the boundary returns a status.  q = 5, 7, 17: smallest non-residue, 2-adicity and root as the oracle derives them."""
+    from oracle import pyref as P
+    with pytest.raises(fhe.FheError):
+        fhe.NttContext(3, device=-1)
+    for q in (5, 7, 17, 97, 12289):
+        info = fhe.NttContext(q, device=-1).info()
+        g = P.generator(q)
+        s = (q - 1 & -(q - 1)).bit_length() - 1
+        assert (info["g"], info["s"], info["omega"]) == (g, s, pow(g, (q - 1) >> s, q))
