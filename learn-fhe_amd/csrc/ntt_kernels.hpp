@@ -98,6 +98,10 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             }
         }
     }
+    // A register-resident transform (REGS_IO) is one of a chain that reuses this LDS image.  Inside a transform a thread only
+    // ever overwrites elements it read itself, but the NEXT user's first writes follow another ownership layout: when several
+    // waves share the image they must all have finished this last read first.  (One wave: its LDS operations complete in order.)
+    if constexpr (last && !first && REGS_IO && !WAVE) __syncthreads();
     // butterflies; lazy values are folded back at a pass boundary only when the policy's reduction-free budget (CT_LAYERS) is
     // smaller than the whole transform: 54-bit pseudo-Mersenne moduli run all log2 N <= 13 layers without a single fold
     // (values < (2 log2 N + 1) q < 2^59), 60-bit ones fold at every boundary
@@ -218,6 +222,7 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
             }
         }
     }
+    if constexpr (final_pass && C::P > 1 && REGS_IO && !WAVE) __syncthreads();  // as in fwd_run: the image is reused by the next transform
     static_for<0, G>([&](auto gg_c) {
         constexpr int gg = decltype(gg_c)::value;
         const int top = pass_top<LOG_N, L0, R, C::T>(t + C::T * gg);
