@@ -176,21 +176,22 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
 
 namespace {
 // the RNS kernels keep their limb vectors in registers: instantiate for the smallest bound that holds the source base
-#define RNS_BOUND(la, CALL)            \
-    do {                               \
-        if ((la) <= 4) { CALL(4); }    \
-        else if ((la) <= 8) { CALL(8); } \
-        else if ((la) <= 16) { CALL(16); } \
-        else { CALL(32); }             \
+#define RNS_BOUND(la, CALL)                                              \
+    do {                                                                 \
+        if ((la) == 8) { CALL(8, true); } /* the BASELINE shape: no limb predicates at all */ \
+        else if ((la) <= 4) { CALL(4, false); }                          \
+        else if ((la) <= 8) { CALL(8, false); }                          \
+        else if ((la) <= 16) { CALL(16, false); }                        \
+        else { CALL(32, false); }                                        \
     } while (0)
 void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, hipStream_t st) {
-#define CALL(M) hipLaunchKernelGGL(fhe::rns_extend_kernel<M>, dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C)
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C)
     RNS_BOUND(C.la, CALL);
 #undef CALL
 }
 void launch_rescale(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
                     const fhe::RescaleConsts &R, hipStream_t st) {
-#define CALL(M) hipLaunchKernelGGL(fhe::rns_rescale_kernel<M>, dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
     RNS_BOUND(R.K, CALL);
 #undef CALL
 }

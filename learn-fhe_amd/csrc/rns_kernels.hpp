@@ -8,6 +8,15 @@ namespace fhe {
 
 constexpr int RNS_MAX_LIMBS = 32;
 
+// The conversion tables are written once at context creation and only ever read by kernels: reading them through the CONSTANT
+// address space lets hipcc use scalar loads (one per wave, batched into s_load_dwordx8/x16 over the unrolled limb loops) where
+// a plain global pointer forced a 64-lane vector load of one address per constant -- 248 dependent vector loads per thread
+// were what bounded the rescale kernel (400 us per 64 cfg4 ciphertexts).
+template <class T>
+__device__ __forceinline__ T ldc(const T *p, int i) {
+    return ((const __attribute__((address_space(4))) T *)p)[i];
+}
+
 // conversion from base A (la moduli) to base B (lb moduli); all tables in HBM
 struct BaseConv {
     int la, lb;
@@ -26,15 +35,15 @@ struct BaseConv {
 // put v[] / vs[] in scratch memory (measured: 57 us -> see DESIGN.md 4.5 for the cfg4 rescale).
 //
 // vs_i = v_i * ahat_inv_i mod a_i; u = round(sum_i frac_i * vs_i) with the reference's sequential f64 sum
-template <int MAXA>
+template <int MAXA, bool FULL>
 __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&v)[MAXA], u64 (&vs)[MAXA]) {
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        if (i < C.la) {
-            const u64 a = C.a_mod[i];
-            vs[i] = csub(mul_shoup_lazy(v[i], C.ahat_inv[i], C.ahat_inv_s[i], a), a);
-            acc = __dadd_rn(acc, __dmul_rn(C.frac[i], (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
+        if (FULL || i < C.la) {
+            const u64 a = ldc(C.a_mod, i);
+            vs[i] = csub(mul_shoup_lazy(v[i], ldc(C.ahat_inv, i), ldc(C.ahat_inv_s, i), a), a);
+            acc = __dadd_rn(acc, __dmul_rn(ldc(C.frac, i), (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
         } else {
             vs[i] = 0;
         }
@@ -43,20 +52,21 @@ __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&
 }
 
 // sum_i c_ji * vs_i - ua_j[u]  (mod b_j), canonical
-template <int MAXA>
+template <int MAXA, bool FULL>
 __device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 (&vs)[MAXA], int u) {
-    const u64 b = C.b_mod[j], b2 = 2 * b;
+    const int la = FULL ? MAXA : C.la;  // FULL: the source base has exactly MAXA limbs -- no predicate, constant strides
+    const u64 b = ldc(C.b_mod, j), b2 = 2 * b;
     u64 dot = 0;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i)
-        if (i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], C.c[j * C.la + i], C.c_s[j * C.la + i], b), b2);
+        if (FULL || i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], ldc(C.c, j * la + i), ldc(C.c_s, j * la + i), b), b2);
     dot = csub(dot, b);
-    const u64 sub = C.ua[j * (C.la + 1) + u];
+    const u64 sub = C.ua[j * (la + 1) + u];  // (u differs per lane: a vector load)
     return dot >= sub ? dot - sub : dot + b - sub;
 }
 
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
-template <int MAXA>
+template <int MAXA, bool FULL>
 __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
                                   BaseConv C) {
     const size_t total = n * batch;
@@ -64,9 +74,15 @@ __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 
         const size_t p = idx / n, i = idx - p * n;
         u64 v[MAXA], vs[MAXA];
 #pragma unroll
-        for (int l = 0; l < MAXA; ++l) v[l] = l < C.la ? in[p * in_bs + size_t(l) * n + i] : 0;
-        const int u = base_conv_prepare(C, v, vs);
-        for (int j = 0; j < C.lb; ++j) out[p * out_bs + size_t(j) * n + i] = base_conv_out(C, j, vs, u);
+        for (int l = 0; l < MAXA; ++l) v[l] = (FULL || l < C.la) ? in[p * in_bs + size_t(l) * n + i] : 0;
+        const int u = base_conv_prepare<MAXA, FULL>(C, v, vs);
+        // output limbs in independent chains of up to MAXA at a time (the bound that serves the source base serves the target
+        // base of the BASELINE shapes too): the unrolled bodies give the scheduler eight dot products to interleave
+        for (int j0 = 0; j0 < C.lb; j0 += MAXA) {
+#pragma unroll
+            for (int jj = 0; jj < MAXA; ++jj)
+                if (j0 + jj < C.lb) out[p * out_bs + size_t(j0 + jj) * n + i] = base_conv_out<MAXA, FULL>(C, j0 + jj, vs, u);
+        }
     }
 }
 
@@ -81,7 +97,7 @@ struct RescaleConsts {
 
 // util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
-template <int MAXA>
+template <int MAXA, bool FULL>
 __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
                                    const u64 *addend, size_t add_bs, size_t n, size_t batch, RescaleConsts R) {
     const size_t total = n * batch;
@@ -89,24 +105,29 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
         const size_t p = idx / n, i = idx - p * n;
         u64 vp[MAXA], vs[MAXA];
 #pragma unroll
-        for (int j = 0; j < MAXA; ++j) vp[j] = j < R.K ? csub(in[p * in_bs + size_t(R.L + j) * n + i] + R.half_p[j], R.p_mod[j]) : 0;
+        for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < R.K) ? csub(in[p * in_bs + size_t(R.L + j) * n + i] + ldc(R.half_p, j), ldc(R.p_mod, j)) : 0;
         int u = 0;
-        if (R.K > 1) u = base_conv_prepare(R.p2q, vp, vs);
-        for (int l = 0; l < R.L; ++l) {
-            const u64 q = R.q_mod[l];
-            const u64 vq = csub(in[p * in_bs + size_t(l) * n + i] + R.half_q[l], q);
+        if (R.K > 1) u = base_conv_prepare<MAXA, FULL>(R.p2q, vp, vs);
+        for (int l0 = 0; l0 < R.L; l0 += MAXA) {
+#pragma unroll
+          for (int ll = 0; ll < MAXA; ++ll) {
+            const int l = l0 + ll;
+            if (l >= R.L) continue;
+            const u64 q = ldc(R.q_mod, l);
+            const u64 vq = csub(in[p * in_bs + size_t(l) * n + i] + ldc(R.half_q, l), q);
             u64 sw;
             if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
                 const u64 x = vp[0];
-                sw = x - __umul64hi(x, R.red_mu[l]) * q;
+                sw = x - __umul64hi(x, ldc(R.red_mu, l)) * q;
                 sw = csub(csub(sw, q), q);
             } else {
-                sw = base_conv_out(R.p2q, l, vs, u);
+                sw = base_conv_out<MAXA, FULL>(R.p2q, l, vs, u);
             }
             const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
-            u64 r = csub(mul_shoup_lazy(diff, R.pinv[l], R.pinv_s[l], q), q);
+            u64 r = csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
             if (addend) r = csub(r + addend[p * add_bs + size_t(l) * n + i], q);
             out[p * out_bs + size_t(l) * n + i] = r;
+          }
         }
     }
 }
