@@ -184,6 +184,14 @@ namespace {
         else if ((la) <= 16) { CALL(16, false); }                        \
         else { CALL(32, false); }                                        \
     } while (0)
+// grid of the limb-wise products: x over the coefficients of one polynomial, y over (ciphertext, limb) pairs
+struct PointwiseGrid {
+    dim3 g;
+    PointwiseGrid(size_t n, size_t polys) {
+        const size_t gx = (n + 255) / 256;
+        g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
+    }
+};
 void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, hipStream_t st) {
 #define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C)
     RNS_BOUND(C.la, CALL);
@@ -265,8 +273,9 @@ int fhe_rns_pointwise_mul(const fhe_rns_ctx *r, int extended, uint64_t *a, const
     const size_t limbs = size_t(extended ? r->L + r->K : r->L), count = n * batch * limbs;
     Mirror ma(a, count, mem, true, st), mb(b, count, mem, true, st);
     if (ma.rc | mb.rc) return FHE_ERR_HIP;
-    hipLaunchKernelGGL(fhe::rns_pointwise_kernel, dim3(grid_for(count)), dim3(256), 0, st, ma.d, (const u64 *)mb.d, n, (int)limbs, batch,
-                       (const fhe::Barrett *)r->d_barrett);
+    if (n >> 31) return FHE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fhe::rns_pointwise_kernel, PointwiseGrid(n, batch * limbs).g, dim3(256), 0, st, ma.d, (const u64 *)mb.d, (unsigned)n,
+                       (unsigned)limbs, batch * limbs, (const fhe::Barrett *)r->d_barrett);
     HIP_TRY(hipGetLastError());
     return ma.sync_out(st);
 }
@@ -336,8 +345,8 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
     }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
     if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, dim3(grid_for(blk)), dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
-                           (const u64 *)key->d_ka, pb, pa, n, (int)lk, batch, (const fhe::Barrett *)r->d_barrett);
+        hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, PointwiseGrid(n, batch * lk).g, dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
+                           (const u64 *)key->d_ka, pb, pa, (unsigned)n, (unsigned)lk, batch * lk, (const fhe::Barrett *)r->d_barrett);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     // pb and pa are adjacent: one inverse launch over 2 * batch * lk polynomials

@@ -132,26 +132,33 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
     }
 }
 
-// ob = kb (.) e, oa = ka (.) e limb-wise in the evaluation domain; e, ob, oa: [batch][lk][n]; kb, ka: [lk][n]
+// ob = kb (.) e, oa = ka (.) e limb-wise in the evaluation domain; e, ob, oa: [batch][lk][n]; kb, ka: [lk][n].
+// blockIdx.y = (ciphertext, limb): the limb's Barrett constants come from scalar loads and no thread divides anything
 FHE_HEADER_KERNEL void rns_pointwise2_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
-                                      u64 *__restrict__ ob, u64 *__restrict__ oa, size_t n, int lk, size_t batch,
-                                      const Barrett *__restrict__ B) {
-    const size_t per = n * size_t(lk), total = per * batch;
-    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
-        const size_t within = idx % per;
-        const Barrett b = B[within / n];
-        const u64 x = e[idx];
-        ob[idx] = mulmod_barrett(x, kb[within], b);
-        oa[idx] = mulmod_barrett(x, ka[within], b);
+                                             u64 *__restrict__ ob, u64 *__restrict__ oa, unsigned n, unsigned lk, size_t polys,
+                                             const Barrett *__restrict__ B) {
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const unsigned limb = unsigned(y % lk);
+        const Barrett b{ldc(&B[limb].q, 0), ldc(&B[limb].mu, 0), ldc(&B[limb].sh1, 0), ldc(&B[limb].sh2, 0)};
+        const size_t base = y * n, kbase = size_t(limb) * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 x = e[base + i];
+            ob[base + i] = mulmod_barrett(x, kb[kbase + i], b);
+            oa[base + i] = mulmod_barrett(x, ka[kbase + i], b);
+        }
     }
 }
 
 // util/src/ring/rns.rs:148-158 `RnsRq *= &RnsRq` (evaluation basis): a[b][l][i] <- a[b][l][i] * b[b][l][i] mod m_l, limbs-major
-FHE_HEADER_KERNEL void rns_pointwise_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t n, int limbs, size_t batch,
+FHE_HEADER_KERNEL void rns_pointwise_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, unsigned n, unsigned limbs, size_t polys,
                                             const Barrett *__restrict__ B) {
-    const size_t per = n * size_t(limbs), total = per * batch;
-    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x)
-        a[idx] = mulmod_barrett(a[idx], b[idx], B[(idx % per) / n]);
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const unsigned limb = unsigned(y % limbs);
+        const Barrett m{ldc(&B[limb].q, 0), ldc(&B[limb].mu, 0), ldc(&B[limb].sh1, 0), ldc(&B[limb].sh2, 0)};
+        const size_t base = y * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+            a[base + i] = mulmod_barrett(a[base + i], b[base + i], m);
+    }
 }
 
 }  // namespace fhe
