@@ -16,13 +16,14 @@
 //   pass 2: regs {5..2   | 1}    thread = bits 13..6, 0       layers 8..11
 //   pass 3: regs {1,0 | 13..11}  thread = bits 10..2          layers 12..13  HBM side: 32 contiguous bytes per lane
 //
-// The forward transform runs passes 0 -> 3 (Cooley-Tukey), the inverse 3 -> 0 (Gentleman-Sande, then * n^-1).
+// The forward transform runs passes 0 -> 3 (Cooley-Tukey), the inverse 3 -> 0 (Gentleman-Sande; n^-1 is folded into its
+// last layer).
 // Natural-order coefficients <-> bit-reversed evaluations, twiddle tw[2^layer + block], exactly as the reference.
 //
 // Arithmetic is a policy: ArithShoup (any prime < 2^62: Shoup multiplication + Harvey lazy reduction) or ArithPM
 // (pseudo-Mersenne primes q = 2^b - c, c <= 2^(b-33), b <= 60 -- every prime `two_adic_primes(bits, log_n)` yields for
-// the BASELINE configs: 7 full 32x32->64 multiply-adds per product on half-width twiddle limbs, no companion table, no
-// compare/select anywhere in a butterfly).  Both end with canonical values in [0, q): bit-identical results.
+// the BASELINE configs: 8 v_mad_u64_u32 + 4 other instructions per product on an 8-byte twiddle, no companion table, no
+// compare/select anywhere in a butterfly; arith.hpp).  Both end with canonical values in [0, q): bit-identical results.
 #pragma once
 #include "ntt_kernels.hpp"
 
