@@ -208,6 +208,26 @@ def test_throughput_and_small_batch_shapes_agree(fhe, cref, torch_cuda, q, log_n
     assert np.array_equal(host(oa)[big - 1], ea) and np.array_equal(host(ob)[big - 1], eb)
 
 
+def test_blind_rotate_large_batch_is_deterministic(fhe, cref, torch_cuda):
+    """cfg3 ring, 1024 ciphertexts (every SIMD busy with two-wave teams sharing LDS images): two runs agree bit for bit, a
+    sample agrees with the small-batch instantiation and one ciphertext with the oracle"""
+    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 1024, 6, 9, 10, 24, 1024
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, lb, d, w, n_lwe, seed=110)
+    rng = np.random.Generator(np.random.PCG64(111))
+    lwe_a = (rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_b = rng.integers(0, 2 * n, size=batch, dtype=np.uint64)
+    f = rand_u64(112, q, n)
+    da, db, df = dev(torch_cuda, lwe_a), dev(torch_cuda, lwe_b), dev(torch_cuda, f)
+    o1 = bk.blind_rotate(da, db, df)
+    o2 = bk.blind_rotate(da, db, df)
+    assert torch_cuda.equal(o1[0], o2[0]) and torch_cuda.equal(o1[1], o2[1])
+    pick = [0, 511, 1023]
+    s = bk.blind_rotate(dev(torch_cuda, lwe_a[pick]), dev(torch_cuda, lwe_b[pick]), df)
+    assert np.array_equal(host(o1[0])[pick], host(s[0])) and np.array_equal(host(o1[1])[pick], host(s[1]))
+    ea, eb = cref.blind_rotate(q, n, w, lb, d, lb, d, brk, ak, ts, f, lwe_a[777], int(lwe_b[777]))
+    assert np.array_equal(host(o1[0])[777], ea) and np.array_equal(host(o1[1])[777], eb)
+
+
 def test_blind_rotate_golden(fhe, torch_cuda):
     v = load_golden("blind_rotate.json")
     q, n, w, lb, d = v["q"], v["n"], v["w"], v["log_b"], v["d"]
