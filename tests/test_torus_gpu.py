@@ -204,3 +204,25 @@ def test_tlwe_key_switch_tiles(fhe, torch_cuda):
         for i in list(range(0, batch, 101)) + [batch - 2, batch - 1]:
             ya, yb = P.tlwe_key_switch(dec, ksa, ksb, L(a[i]), int(b[i]))
             assert L(ha[i]) == ya and int(hb[i]) == yb, (batch, i)
+
+
+def test_blind_rotate_large_batch_is_deterministic(fhe, torch_cuda):
+    """cfg5 ring (N = 1024, base 2^7, d = 3), 1024 ciphertexts: every SIMD busy with multi-wave teams sharing LDS images; two runs
+    agree bit for bit, and a sample agrees with the same ciphertexts run as a small batch"""
+    n, n_lwe, log_b, d, batch = 1024, 12, 7, 3, 1024
+    gen = torch_cuda.Generator(device="cuda")
+    gen.manual_seed(7)
+    rnd = lambda *shape: torch_cuda.randint(-(1 << 63), (1 << 63) - 1, shape, dtype=torch_cuda.int64, device="cuda", generator=gen)  # noqa: E731
+    t = fhe.TorusContext()
+    key = fhe.TggswKey(t, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n)
+    v = rnd(n)
+    at = fhe.TorusContext.mod_switch(rnd(batch, n_lwe), n)
+    bt = fhe.TorusContext.mod_switch(rnd(batch), n)
+    at[5, :] = 0                                   # a ciphertext every CMUX of which short-circuits
+    o1 = key.blind_rotate(at, bt, v)
+    o2 = key.blind_rotate(at, bt, v)
+    assert torch_cuda.equal(o1[0], o2[0]) and torch_cuda.equal(o1[1], o2[1])
+    pick = [0, 5, 1023]
+    s = key.blind_rotate(at[pick].contiguous(), bt[pick].contiguous(), v)
+    assert torch_cuda.equal(o1[0][pick], s[0]) and torch_cuda.equal(o1[1][pick], s[1])
+    assert int(o1[0][5].abs().max()) == 0          # (0, v X^-b) untouched: a stays zero
