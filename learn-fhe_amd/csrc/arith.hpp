@@ -48,6 +48,7 @@ struct ModDesc {
 };
 
 struct ArithShoup {
+    typedef u64 Elem;  // the integer type a coefficient occupies in registers, LDS and HBM
     struct K {
         u64 q, q2;
         const FHE_GLOBAL TwPair *tw, *twi;
@@ -170,6 +171,7 @@ __device__ __forceinline__ u64 pm_mul(u64 y, const PmTw w, const PmK &k) {
 // B = bit length of q (compile time: every shift and mask is an immediate)
 template <int B>
 struct ArithPM {
+    typedef u64 Elem;
     static constexpr u64 MASK = (u64(1) << B) - 1;
     struct K {
         PmK m;
@@ -307,7 +309,7 @@ __device__ __forceinline__ void tw_load(typename A::TwRaw (&raw)[NTW], int top, 
 }
 
 template <class A, class U, int NTW, int E>
-__device__ __forceinline__ void ct_apply(u64 (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
+__device__ __forceinline__ void ct_apply(typename A::Elem (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
     // lazy policies bound how many layers may run between two folds (multiplicands must stay below 2^63)
     if constexpr (U::l > 0 && U::l % A::CT_LAYERS == 0) {
 #pragma unroll
@@ -345,7 +347,7 @@ __device__ __forceinline__ void ct_apply(u64 (&x)[E], const typename A::TwRaw (&
 // inverse: the unit of layer l is step R-1-l of its network; PH = step & 1 pairs layers for the lazy policies, sums are
 // folded after every second layer and after the last layer of a network with an odd layer count
 template <class A, class U, int NTW, int E>
-__device__ __forceinline__ void gs_apply(u64 (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
+__device__ __forceinline__ void gs_apply(typename A::Elem (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
     constexpr int step = U::R - 1 - U::l, PH = step & 1;
     constexpr bool FOLD = A::GS_FOLDS && (PH == 1 || step == U::R - 1);
     static_for<0, (U::SHARED ? (1 << U::l) : U::NREP)>([&](auto oc) {
@@ -367,7 +369,7 @@ __device__ __forceinline__ void gs_apply(u64 (&x)[E], const typename A::TwRaw (&
 // one whole network with just-in-time twiddles (a layer's loads stay inside that layer): the generic kernels, the
 // 2^15..2^17 passes and the wave-per-ciphertext FHEW kernels
 template <class A, int L0, int R, int OFF, int E>
-__device__ __forceinline__ void ct_net(u64 (&x)[E], int top, const typename A::K &k) {
+__device__ __forceinline__ void ct_net(typename A::Elem (&x)[E], int top, const typename A::K &k) {
     static_for<0, R>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         typedef Unit<L0, R, l, 1, 1, OFF, true> U;  // one replica at register offset REP0 * STRIDE = OFF
@@ -379,7 +381,7 @@ __device__ __forceinline__ void ct_net(u64 (&x)[E], int top, const typename A::K
 }
 
 template <class A, int L0, int R, int OFF, int E>
-__device__ __forceinline__ void gs_net(u64 (&x)[E], int top, const typename A::K &k) {
+__device__ __forceinline__ void gs_net(typename A::Elem (&x)[E], int top, const typename A::K &k) {
     static_for<0, R>([&](auto sc) {
         constexpr int l = R - 1 - decltype(sc)::value;
         typedef Unit<L0, R, l, 1, 1, OFF, true> U;

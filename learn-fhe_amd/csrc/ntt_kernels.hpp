@@ -78,7 +78,8 @@ __device__ __forceinline__ void exchange_sync() {
 // x[r]), still lazy in [0, 4q); nothing touches global memory.
 // ---------------------------------------------------------------------------------------------
 template <class A, typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>
-__device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
+__device__ __forceinline__ void fwd_run(typename A::Elem (&x)[1 << LOG_E], int t, typename A::Elem *__restrict__ g, typename A::Elem *lds,
+                                        bool active,
                                         const typename A::K &k) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (L0 == 0) ? C::R0 : LOG_E;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void fwd_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
-                u64 v = x[gg * (1 << R) + r];
+                typename A::Elem v = x[gg * (1 << R) + r];
                 if constexpr (last) v = A::canon_fwd(v, k);
                 lds[lds_phys(pass_index<LOG_N, L0, R>(t + C::T * gg, r))] = v;
             }
@@ -191,7 +192,8 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 // REGS_IO: x[] comes in in the last-layer pass layout (coefficient t*E + r at x[r], values in [0, 2q)) and
 // leaves in the first-pass layout, multiplied by n^-1 and canonical.
 template <class A, typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>  // layers [L0, LEND)
-__device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__restrict__ g, u64 *lds, bool active,
+__device__ __forceinline__ void inv_run(typename A::Elem (&x)[1 << LOG_E], int t, typename A::Elem *__restrict__ g, typename A::Elem *lds,
+                                        bool active,
                                         const typename A::K &k) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (LEND == C::R0) ? C::R0 : LOG_E;
@@ -236,7 +238,7 @@ __device__ __forceinline__ void inv_run(u64 (&x)[1 << LOG_E], int t, u64 *__rest
         for (int gg = 0; gg < G; ++gg)
 #pragma unroll
             for (int r = 0; r < (1 << R); ++r) {
-                const u64 v = A::finish_inv(x[gg * (1 << R) + r], k);
+                const typename A::Elem v = A::finish_inv(x[gg * (1 << R) + r], k);
                 if constexpr (REGS_IO) x[gg * (1 << R) + r] = v;
                 else if (active) gstore(g, pass_index<LOG_N, L0, R>(t + C::T * gg, r), v);
             }

@@ -8,12 +8,16 @@
 #include "ctx.hpp"
 #include "torus_kernels.hpp"
 #include "lwe_kernels.hpp"
+#include "torus30_kernels.hpp"
 
 struct fhe_torus_ctx {
     int device = -1;
     fhe_ctx *mods[2] = {nullptr, nullptr};
     fhe::ModDesc *d_descs = nullptr;  // [2]
     fhe::TorusConsts T{};
+    // the three-prime 30-bit path (torus30_kernels.hpp)
+    void *d_blob30 = nullptr;         // twiddle tables + descriptors
+    fhe::Torus30Consts T30{};
 };
 
 struct fhe_tggsw_key {
@@ -21,6 +25,7 @@ struct fhe_tggsw_key {
     int log_n = 0, log_b = 0, d = 0;
     size_t count = 0;
     u64 *d_rows[2] = {nullptr, nullptr};  // per prime: [count][2d][2][N] evaluation domain, key_perm layout
+    unsigned *d_rows30 = nullptr;         // 30-bit path: [3 primes][count][2d][2][N] Montgomery residues, key_perm30 layout
     fhe::TDecomp P{};
 };
 
@@ -46,6 +51,47 @@ inline unsigned grid_for(size_t total) {
     return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
 }
 
+// ---- the three 30-bit primes of the torus30 path: the largest p < 2^30 with p = 1 (mod 2^12) ----
+constexpr int T30_LOG_CAP = 11;  // tables for rings up to N = 2^11
+struct Host30 {
+    uint32_t p[3];
+    std::vector<uint2> tw[3], twi[3];
+    fhe::Mod30Desc desc[3];
+};
+inline uint32_t shoup32(uint64_t w, uint64_t p) { return (uint32_t)((w << 32) / p); }
+void build_host30(Host30 &H) {
+    int found = 0;
+    for (uint64_t k = ((uint64_t(1) << 30) - 1) >> 12; k > 0 && found < 3; --k) {
+        const uint64_t p = (k << 12) + 1;
+        if (fhe::is_prime_u64(p)) H.p[found++] = (uint32_t)p;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t p = H.p[i];
+        const uint64_t g = fhe::smallest_nonresidue(p);
+        const uint64_t psi = fhe::powmod(g, (p - 1) >> (T30_LOG_CAP + 1), p), psi_inv = fhe::invmod(psi, p);  // primitive 2^12-th root
+        const size_t cap = size_t(1) << T30_LOG_CAP;
+        std::vector<uint64_t> pw(cap), pwi(cap);
+        uint64_t x = 1, y = 1;
+        for (size_t j = 0; j < cap; ++j) { pw[j] = x; pwi[j] = y; x = fhe::mulmod(x, psi, p); y = fhe::mulmod(y, psi_inv, p); }
+        H.tw[i].resize(cap); H.twi[i].resize(cap);
+        for (size_t j = 0; j < cap; ++j) {
+            const size_t r = fhe::bitrev((unsigned)j, T30_LOG_CAP);
+            H.tw[i][j] = uint2{(uint32_t)pw[r], shoup32(pw[r], p)};
+            H.twi[i][j] = uint2{(uint32_t)pwi[r], shoup32(pwi[r], p)};
+        }
+        fhe::Mod30Desc &D = H.desc[i];
+        D.p = (uint32_t)p;
+        for (int k = 0; k < 12; ++k) {
+            const uint64_t ni = fhe::invmod((uint64_t(1) << k) % p, p);
+            D.ninv[k] = (uint32_t)ni; D.ninv_s[k] = shoup32(ni, p);
+        }
+        uint32_t inv = 1;  // p^-1 mod 2^32 by Newton iteration
+        for (int it = 0; it < 5; ++it) inv *= 2 - (uint32_t)p * inv;
+        D.pinv_neg = 0u - inv;
+        D.r2 = (uint32_t)((((fhe::u128)1) << 64) % p);
+    }
+}
+
 // the team shape of the torus kernels per ring degree: 4 coefficients per lane from N = 1024 up (the state of a CMUX -- accumulator,
 // difference, digit state, two unreduced sum pairs -- is heavier than FHEW's; measured at cfg5: 17.2-17.3 k gates/s against
 // 16.6-16.9 k with 8 per lane, same session, and the better shape for small batches as well)
@@ -68,6 +114,19 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
                 size_t rot_stride, hipStream_t st) {
     const size_t n = size_t(1) << key->log_n;
     const size_t per = size_t(2 * key->d) * 2 * n;
+    if (key->d_rows30) {  // three 30-bit primes
+        const size_t plane = key->count * per;
+        TORUS_DISPATCH(key->log_n, {
+            typedef TorusRing<LN> WR;
+            const size_t lds = WR::TORUS_LDS_BYTES;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_cmux_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fhe::torus30_cmux_kernel<WR>, dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), lds, st, a, b,
+                               (unsigned)batch, (const unsigned *)(key->d_rows30 + index * per), plane, key->P, rot, rot_stride, t->T30);
+        });
+        HIP_TRY(hipGetLastError());
+        return FHE_OK;
+    }
     const u64 *rows0 = key->d_rows[0] + index * per, *rows1 = key->d_rows[1] + index * per;
     TORUS_DISPATCH(key->log_n, {
         const size_t lds = TorusRing<LN>::TORUS_LDS_BYTES;
@@ -89,6 +148,7 @@ void fhe_torus_ctx_destroy(fhe_torus_ctx *t) {
     if (t->device >= 0) {
         DeviceGuard guard(t->device);
         if (t->d_descs) (void)hipFree(t->d_descs);
+        if (t->d_blob30) (void)hipFree(t->d_blob30);
     }
     fhe_ctx_destroy(t->mods[0]);
     fhe_ctx_destroy(t->mods[1]);
@@ -119,6 +179,36 @@ int fhe_torus_ctx_create(int device, fhe_torus_ctx **out) {
     t->T.P_lo = (uint64_t)P;
     t->T.Ph_hi = (uint64_t)(Ph >> 64); t->T.Ph_lo = (uint64_t)Ph;
     t->T.B0 = t->mods[0]->barrett; t->T.B1 = t->mods[1]->barrett;
+    {   // three-prime 30-bit path: tables [3][tw | twi][2^11] uint2, then the three descriptors
+        Host30 H;
+        build_host30(H);
+        const size_t cap = size_t(1) << T30_LOG_CAP, tbytes = cap * sizeof(uint2);
+        const size_t blob = 6 * tbytes + 3 * sizeof(fhe::Mod30Desc);
+        e = hipMalloc(&t->d_blob30, blob);
+        if (e != hipSuccess) { g_last_hip = (int)e; fhe_torus_ctx_destroy(t); return FHE_ERR_HIP; }
+        char *base = (char *)t->d_blob30;
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+            e = hipMemcpy(base + (2 * i) * tbytes, H.tw[i].data(), tbytes, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(base + (2 * i + 1) * tbytes, H.twi[i].data(), tbytes, hipMemcpyHostToDevice);
+            H.desc[i].tw = (const uint2 *)(base + (2 * i) * tbytes);
+            H.desc[i].twi = (const uint2 *)(base + (2 * i + 1) * tbytes);
+        }
+        if (e == hipSuccess) e = hipMemcpy(base + 6 * tbytes, H.desc, 3 * sizeof(fhe::Mod30Desc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { g_last_hip = (int)e; fhe_torus_ctx_destroy(t); return FHE_ERR_HIP; }
+        fhe::Torus30Consts &C = t->T30;
+        C.descs = (const fhe::Mod30Desc *)(base + 6 * tbytes);
+        const uint64_t p0 = H.p[0], p1 = H.p[1], p2 = H.p[2];
+        C.p[0] = H.p[0]; C.p[1] = H.p[1]; C.p[2] = H.p[2];
+        C.inv01 = (uint32_t)fhe::invmod(p0 % p1, p1); C.inv01_s = shoup32(C.inv01, p1);
+        C.inv02 = (uint32_t)fhe::invmod(p0 % p2, p2); C.inv02_s = shoup32(C.inv02, p2);
+        C.inv12 = (uint32_t)fhe::invmod(p1 % p2, p2); C.inv12_s = shoup32(C.inv12, p2);
+        C.p01 = p0 * p1;
+        const fhe::u128 P3 = (fhe::u128)C.p01 * p2, half = P3 >> 1;
+        C.P_lo = (uint64_t)P3;
+        C.h0 = (uint32_t)(half % p0);
+        C.h1 = (uint32_t)((half / p0) % p1);
+        C.h2 = (uint32_t)(half / p0 / p1);
+    }
     *out = t;
     return FHE_OK;
 }
@@ -178,6 +268,7 @@ void fhe_tggsw_key_destroy(fhe_tggsw_key *k) {
     if (k->t && k->t->device >= 0) {
         DeviceGuard guard(k->t->device);
         if (k->d_rows[0]) (void)hipFree(k->d_rows[0]);
+        if (k->d_rows30) (void)hipFree(k->d_rows30);
     }
     delete k;
 }
@@ -194,39 +285,58 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     fhe::TDecomp P;
     int rc = make_tdecomp(log_b, d, &P);
     if (rc != FHE_OK) return rc;
-    // exactness of the two-prime product: 2d * N * 2^(62 + log_b) < p0 p1 / 2 ~ 2^118.9
-    if (ilog2((size_t)2 * d) + 1 + log_n + 62 + log_b > 118) return FHE_ERR_UNSUPPORTED;
+    // exactness: |coefficient| <= 2d * N * 2^(log_b - 1) * 2^63 must stay below P / 2
+    const int bound_bits = ilog2((size_t)2 * d) + 1 + log_n + 62 + log_b;
+    if (bound_bits > 118) return FHE_ERR_UNSUPPORTED;              // two 60-bit primes: P / 2 ~ 2^118.9
+    const bool use30 = bound_bits <= 88 && log_b <= 28;            // three 30-bit primes: P / 2 ~ 2^88.9 (torus30_kernels.hpp)
     DeviceGuard guard(t->device);
     if (!guard.ok) return FHE_ERR_HIP;
     const size_t rows = count * 2 * d, words = rows * n;
     hipStream_t st = nullptr;
     u64 *src = nullptr, *tmp = nullptr, *dst = nullptr;
+    unsigned *dst30 = nullptr;
     HIP_TRY(hipMalloc((void **)&src, 2 * words * sizeof(u64)));
-    hipError_t e = hipMalloc((void **)&tmp, 2 * words * sizeof(u64));
-    if (e == hipSuccess) e = hipMalloc((void **)&dst, 4 * words * sizeof(u64));  // both primes
     hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (e == hipSuccess) e = hipMemcpyAsync(src, rows_a, words * sizeof(u64), kind, st);
+    hipError_t e = hipMemcpyAsync(src, rows_a, words * sizeof(u64), kind, st);
     if (e == hipSuccess) e = hipMemcpyAsync(src + words, rows_b, words * sizeof(u64), kind, st);
     rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (e != hipSuccess) g_last_hip = (int)e;
-    for (int pi = 0; pi < 2 && rc == FHE_OK; ++pi) {
-        hipLaunchKernelGGL(fhe::torus_residue_kernel, dim3(grid_for(2 * words)), dim3(256), 0, st, (const u64 *)src, tmp, 2 * words,
-                           pi ? t->T.p1 : t->T.p0);
-        if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
-        rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
-        if (rc != FHE_OK) break;
-        TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<TorusRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
-                                                 (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows, 60));
-        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK && use30) {
+        if (hipMalloc((void **)&dst30, 3 * 2 * words * sizeof(unsigned)) != hipSuccess) rc = FHE_ERR_HIP;
+        for (int pi = 0; pi < 3 && rc == FHE_OK; ++pi) {
+            TORUS_DISPATCH(log_n, {
+                typedef TorusRing<LN> WR;
+                if (WR::LDS_BYTES > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_key_prepare_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR::LDS_BYTES));
+                hipLaunchKernelGGL(fhe::torus30_key_prepare_kernel<WR>, dim3((unsigned)((2 * rows + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
+                                   WR::LDS_BYTES, st, (const u64 *)src, (const u64 *)(src + words), rows, t->T30.descs + pi,
+                                   dst30 + size_t(pi) * 2 * words);
+            });
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+    } else if (rc == FHE_OK) {
+        e = hipMalloc((void **)&tmp, 2 * words * sizeof(u64));
+        if (e == hipSuccess) e = hipMalloc((void **)&dst, 4 * words * sizeof(u64));  // both primes
+        if (e != hipSuccess) { g_last_hip = (int)e; rc = FHE_ERR_HIP; }
+        for (int pi = 0; pi < 2 && rc == FHE_OK; ++pi) {
+            hipLaunchKernelGGL(fhe::torus_residue_kernel, dim3(grid_for(2 * words)), dim3(256), 0, st, (const u64 *)src, tmp, 2 * words,
+                               pi ? t->T.p1 : t->T.p0);
+            if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
+            rc = fhe::ntt_fwd_multi(t->d_descs + pi, 1, tmp, log_n, 2 * rows, st, 60);
+            if (rc != FHE_OK) break;
+            TORUS_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<TorusRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)tmp,
+                                                     (const u64 *)(tmp + words), dst + size_t(pi) * 2 * words, rows, 60));
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
     (void)hipFree(src);
     if (tmp) (void)hipFree(tmp);
-    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); return rc; }
+    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); return rc; }
     fhe_tggsw_key *k = new (std::nothrow) fhe_tggsw_key();
-    if (!k) { (void)hipFree(dst); return FHE_ERR_INVALID; }
+    if (!k) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); return FHE_ERR_INVALID; }
     k->t = t; k->log_n = log_n; k->log_b = log_b; k->d = d; k->count = count; k->P = P;
-    k->d_rows[0] = dst; k->d_rows[1] = dst + 2 * words;
+    k->d_rows[0] = dst; k->d_rows[1] = dst ? dst + 2 * words : nullptr; k->d_rows30 = dst30;
     *out = k;
     return FHE_OK;
 }
@@ -279,14 +389,27 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     // acc = (0, v).rotate(-b), then fold cmux(brk_i, acc, acc.rotate(a_i)) (bootstrapping.rs:91-95): one launch, the
     // accumulator never leaves the registers of the team that owns the ciphertext
     int rc = FHE_OK;
+    if (brk->d_rows30) {  // three 30-bit primes
+        const size_t plane = brk->count * size_t(2 * brk->d) * 2 * n;
+        TORUS_DISPATCH(brk->log_n, {
+            typedef TorusRing<LN> WR;
+            const size_t lds = WR::TORUS_LDS_BYTES;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_blind_rotate_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fhe::torus30_blind_rotate_kernel<WR>, dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), lds, st,
+                               (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe, (unsigned)batch,
+                               (const unsigned *)brk->d_rows30, plane, brk->P, t->T30, moa.d, mob.d);
+        });
+    } else {
     TORUS_DISPATCH(brk->log_n, {
-        const size_t lds = TorusRing<LN>::TORUS_LDS_BYTES;
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<TorusRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<TorusRing<LN>>, dim3((unsigned)((batch + TorusRing<LN>::TEAMS - 1) / TorusRing<LN>::TEAMS)),
-                           dim3(TorusRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
-                           (unsigned)batch, (const u64 *)brk->d_rows[0], (const u64 *)brk->d_rows[1], brk->P, t->T, moa.d, mob.d);
-    });
+            const size_t lds = TorusRing<LN>::TORUS_LDS_BYTES;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus_blind_rotate_kernel<TorusRing<LN>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fhe::torus_blind_rotate_kernel<TorusRing<LN>>, dim3((unsigned)((batch + TorusRing<LN>::TEAMS - 1) / TorusRing<LN>::TEAMS)),
+                               dim3(TorusRing<LN>::THREADS), lds, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe,
+                               (unsigned)batch, (const u64 *)brk->d_rows[0], (const u64 *)brk->d_rows[1], brk->P, t->T, moa.d, mob.d);
+        });
+    }
     if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
