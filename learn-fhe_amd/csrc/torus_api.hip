@@ -100,6 +100,9 @@ void build_host30(Host30 &H) {
 #endif
 template <int LN>
 using TorusRing = fhe::WaveRing<LN, (LN <= 9 ? LN - 6 : FHE_TORUS_LOG_E)>;
+// the 30-bit path carries half the registers per coefficient: 8 per lane again (22.9 k against 21.8 k gates/s at cfg5)
+template <int LN>
+using TorusRing30 = fhe::WaveRing<LN, (LN <= 9 ? LN - 6 : 3)>;
 
 #define TORUS_DISPATCH(log_n, ...)                                         \
     switch (log_n) {                                                       \
@@ -117,7 +120,7 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
     if (key->d_rows30) {  // three 30-bit primes
         const size_t plane = key->count * per;
         TORUS_DISPATCH(key->log_n, {
-            typedef TorusRing<LN> WR;
+            typedef TorusRing30<LN> WR;
             const size_t lds = WR::TORUS_LDS_BYTES;
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_cmux_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -305,7 +308,7 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
         if (hipMalloc((void **)&dst30, 3 * 2 * words * sizeof(unsigned)) != hipSuccess) rc = FHE_ERR_HIP;
         for (int pi = 0; pi < 3 && rc == FHE_OK; ++pi) {
             TORUS_DISPATCH(log_n, {
-                typedef TorusRing<LN> WR;
+                typedef TorusRing30<LN> WR;
                 if (WR::LDS_BYTES > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_key_prepare_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR::LDS_BYTES));
                 hipLaunchKernelGGL(fhe::torus30_key_prepare_kernel<WR>, dim3((unsigned)((2 * rows + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
@@ -392,7 +395,7 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     if (brk->d_rows30) {  // three 30-bit primes
         const size_t plane = brk->count * size_t(2 * brk->d) * 2 * n;
         TORUS_DISPATCH(brk->log_n, {
-            typedef TorusRing<LN> WR;
+            typedef TorusRing30<LN> WR;
             const size_t lds = WR::TORUS_LDS_BYTES;
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_blind_rotate_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
