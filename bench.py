@@ -126,7 +126,7 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
     """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
     bootstrapping.rs:139-165) at N = 2^10, k = 1: mod switch, n_lwe = 630 CMUXes (base 2^7, d = 3 -- the reference ships
     no N = 2^10 parameter set; these are the usual ones for that ring), sample extract, TLWE key switch (base 2^4, d = 5
-    as in the reference's test).  Exact torus arithmetic (two-prime CRT), uniform-random keys."""
+    as in the reference's test).  Exact torus arithmetic (CRT over three 30-bit primes at this shape), uniform-random keys."""
     n, n_lwe, log_b, d, ks_lb, ks_d = 1024, 630, 7, 3, 4, 5
     t = F.TorusContext(device=local_rank)
     gen = torch.Generator(device=dev)
