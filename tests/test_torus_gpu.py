@@ -226,3 +226,29 @@ def test_blind_rotate_large_batch_is_deterministic(fhe, torch_cuda):
     s = key.blind_rotate(at[pick].contiguous(), bt[pick].contiguous(), v)
     assert torch_cuda.equal(o1[0][pick], s[0]) and torch_cuda.equal(o1[1][pick], s[1])
     assert int(o1[0][5].abs().max()) == 0          # (0, v X^-b) untouched: a stays zero
+
+
+@pytest.mark.parametrize("log_b,d", [(15, 2), (16, 2)])
+def test_external_product_at_the_path_boundary(fhe, torch_cuda, log_b, d):
+    """N = 256: bound 2d N 2^(62 + log_b) = 2^88 (base 2^15: three 30-bit primes) and 2^89 (base 2^16: two 60-bit primes), with
+    WORST-CASE operands -- every key coefficient -2^63 and every digit at its extreme -- so the exact integer coefficients sit as
+    close to P/2 as this shape can bring them; both paths bit-equal to the exact oracle"""
+    from oracle import pyref as P
+    n = 256
+    dec = P.TorusDecomposor(log_b, d)
+    t = fhe.TorusContext()
+    big = 1 << 63
+    ra = [[[big] * n for _ in range(2 * d)]]
+    rb = [[[big if (i + r) % 3 else (1 << 63) - 1 for i in range(n)] for r in range(2 * d)]]
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, U(ra)), dev(torch_cuda, U(rb)), n)
+    # torus values whose every digit is -2^(log_b-1) (the most negative balanced digit): sum_j (-B/2) B^j scaled to the top bits
+    half = 1 << (log_b - 1)
+    v = (-sum(half << (64 - log_b * (j + 1)) for j in range(d))) % (1 << 64)
+    rnd = random.Random(31)
+    ca = [[v] * n, [rnd.getrandbits(64) for _ in range(n)]]
+    cb = [[v] * n, [rnd.getrandbits(64) for _ in range(n)]]
+    a, b = dev(torch_cuda, U(ca)), dev(torch_cuda, U(cb))
+    key.external_product_(0, a, b)
+    for i in range(2):
+        ea, eb = P.tggsw_external_product(dec, ra[0], rb[0], ca[i], cb[i])
+        assert L(host(a)[i]) == ea and L(host(b)[i]) == eb, (log_b, i)
