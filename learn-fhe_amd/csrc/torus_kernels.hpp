@@ -54,22 +54,6 @@ FHE_HEADER_KERNEL void torus_residue_kernel(const u64 *__restrict__ in, u64 *__r
         out[idx] = signed_residue(in[idx], p);
 }
 
-// multiplication by X^k on the torus (ring.rs:299-313, negation = wrapping_neg), per-polynomial shift:
-// k = shift[p * stride] taken mod 2n; neg_shift: use -k (acc.rotate(-b), bootstrapping.rs:93)
-FHE_HEADER_KERNEL void torus_monomial_kernel(const u64 *__restrict__ in, size_t in_stride, u64 *__restrict__ out, unsigned n, size_t batch,
-                                      const u64 *__restrict__ shift, size_t stride, int neg_shift) {
-    const size_t total = size_t(n) * batch;
-    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
-        const size_t p = idx / n;
-        const unsigned j = unsigned(idx - p * n);
-        unsigned k2n = unsigned(shift[p * stride]) & (2 * n - 1);
-        if (neg_shift) k2n = (2 * n - k2n) & (2 * n - 1);
-        const unsigned pos = (j + k2n) & (2 * n - 1);
-        const u64 v = in[p * in_stride + j];
-        out[p * n + (pos & (n - 1))] = pos < n ? v : 0 - v;
-    }
-}
-
 struct TorusConsts {
     const ModDesc *descs;     // two primes p0, p1 (pseudo-Mersenne, 60 bits)
     u64 p0, p1;
