@@ -111,6 +111,13 @@ void fhe_key_destroy(fhe_key *key);
  * (ct_a, ct_b: [batch][n], coefficient domain, in place). */
 int fhe_external_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, uint64_t *ct_a, uint64_t *ct_b,
                          size_t batch, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rgsw.rs:130-150 `Rgsw::internal_product(param, ct0 = rgsw[index], ct1)`: RGSW x RGSW -> RGSW.  The reference
+ * transforms ct0's rows once and takes, for every one of ct1's 2d RLWE rows, the evaluation-domain dot product with that row's
+ * digits -- i.e. the external product of ct0 with each row of ct1.  ct0 is a prepared key (its rows already sit in the
+ * evaluation domain, exactly what lines 136-137 compute); ct1_a / ct1_b: [count][2d][n] (coefficient domain, the layout
+ * fhe_rgsw_prepare takes), replaced in place by the rows of the product, for `count` right-hand RGSW ciphertexts. */
+int fhe_rgsw_internal_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, uint64_t *ct1_a, uint64_t *ct1_b,
+                              size_t count, fhe_mem mem, void *stream);
 /* scheme/fhew/src/rlwe.rs:177-186 `Rlwe::key_switch(param, ksk[index], ct)`. */
 int fhe_rlwe_key_switch(const fhe_ctx *ctx, const fhe_key *ksk, size_t index, uint64_t *ct_a, uint64_t *ct_b,
                         size_t batch, fhe_mem mem, void *stream);

@@ -77,7 +77,7 @@ def lib():
             getattr(L, name).argtypes = [vp, ci, ci, vp, vp, sz, sz, ci, C.POINTER(vp)]
         L.fhe_key_destroy.argtypes = [vp]
         L.fhe_key_destroy.restype = None
-        for name in ("fhe_external_product", "fhe_rlwe_key_switch"):
+        for name in ("fhe_external_product", "fhe_rlwe_key_switch", "fhe_rgsw_internal_product"):
             getattr(L, name).argtypes = [vp, vp, sz, vp, vp, sz, ci, vp]
         L.fhe_rlwe_automorphism.argtypes = [vp, vp, sz, C.c_int64, vp, vp, sz, ci, vp]
         L.fhe_bootstrap_key_create.argtypes = [vp, vp, vp, i64p, ci, C.POINTER(vp)]

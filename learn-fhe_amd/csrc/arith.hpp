@@ -45,6 +45,10 @@ struct ModDesc {
     const u64 *tww, *twwi;
     unsigned pm_c;
     int pm_b;
+    // two-operand split form of the same twiddles (ArithDS): 16-byte entries {a0, a1, b0, b1}, w = a0 + a1 2^(pm_b-31),
+    // w 2^32 mod q = b0 + b1 2^(pm_b-31); ds_pow = 2^(pm_b-31), read from memory so that the compiler keeps the multiply-add
+    const uint4 *twd, *twdi;
+    unsigned ds_pow;
 };
 
 struct ArithShoup {
@@ -89,6 +93,8 @@ struct ArithShoup {
     static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &p, const K &k) { gs_bfly(X, Y, p.w, p.ws, k.q, k.q2); }
     static constexpr bool GS_FOLDS = false;
     static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
+    static constexpr bool PASS_FOLD = false;
+    static __device__ constexpr bool ct_fold_at(int) { return false; }
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return canon4(x, k.q, k.q2); }
@@ -247,6 +253,8 @@ struct ArithPM {
     }
     // forward layers between two folds: inputs < q + eps, a multiplicand of layer L is < (2L - 1) q and must be < 2^63
     static constexpr int CT_LAYERS = ((1 << (63 - B)) + 1) / 2 > 64 ? 64 : ((1 << (63 - B)) + 1) / 2;
+    static constexpr bool PASS_FOLD = true;  // ... and at every pass boundary of a transform longer than that
+    static __device__ constexpr bool ct_fold_at(int) { return false; }
     static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }  // between forward passes
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
@@ -273,6 +281,104 @@ struct ArithPM {
         return acc;
     }
     static __device__ __forceinline__ u64 mac_finish(MacAcc acc, const K &k) { return pm_reduce_vu<B>(acc.v, acc.u, k.m); }  // < q + eps
+};
+
+// Pseudo-Mersenne product on a twiddle kept as TWO fixed operands, q = 2^B - c (c < 2^(B-33), 34 <= B <= 60).
+// The multiplicand is cut at its register boundary, y = y0 + y1 2^32, and the twiddle is stored for both halves:
+//     w0 = w = a0 + a1 2^(B-31),   w1 = w 2^32 mod q = b0 + b1 2^(B-31)      (a0, b0 < 2^(B-31);  a1, b1 < 2^31)
+//     w y = w0 y0 + w1 y1 = S0 + S1 2^(B-31)  (mod q),   S0 = a0 y0 + b0 y1 < 2^(B+2),   S1 = a1 y0 + b1 y1 < 2^64
+//     S1 2^(B-31) = lo32(S1) 2^(B-31) + hi32(S1) 2^(B+1),   2^(B+1) = 2c  (mod q)
+//     R = S0 + lo32(S1) 2^(B-31) + hi32(S1) 2c  <  2^(B+2) + 2^(B+1) + 2^B  <  2^(B+3)               for ANY 64-bit y
+// SIX v_mad_u64_u32 and nothing else (lo32 / hi32 of a register pair are its registers); one fold at bit B (mask the high
+// word, shift it, one more multiply-add) brings R below 2^B + 8c.  A butterfly is 13 instructions where the single-operand
+// form (ArithPM) needs 18: the price is a 16-byte twiddle.
+struct DsK {
+    u64 q, q2, q4;
+    unsigned c, c2, pw;  // c, 2c, 2^(B-31)
+};
+
+template <int B>
+struct ArithDS {
+    typedef u64 Elem;
+    static constexpr u64 MASK = (u64(1) << B) - 1;
+    static constexpr int SPLIT = B - 31;
+    typedef uint4 TwRaw;  // {a0, a1, b0, b1}: the memory form IS the register form
+    typedef uint4 TwReg;
+    struct K {
+        DsK m;
+        const FHE_GLOBAL uint4 *tw, *twi;
+        uint4 ninv, ninv_w;
+        int pb, prefix;
+    };
+    static constexpr int PREFETCH = 4;
+    static __host__ __device__ __forceinline__ uint4 split(u64 w, u64 q) {
+        const u64 w1 = (u64)((((unsigned __int128)w) << 32) % q);
+        const u64 lo = (u64(1) << SPLIT) - 1;
+        return uint4{(unsigned)(w & lo), (unsigned)(w >> SPLIT), (unsigned)(w1 & lo), (unsigned)(w1 >> SPLIT)};
+    }
+    template <bool INV>
+    static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
+        const FHE_GLOBAL uint4 *p = (INV ? k.twi : k.tw) + idx;
+        TwRaw r;
+        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
+        return r;
+    }
+    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return r; }
+    static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
+        K k;
+        k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
+        k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c; k.m.pw = D.ds_pow;
+        k.tw = as_global(D.twd); k.twi = as_global(D.twdi);
+        k.ninv = split(pb ? 1 : D.ninv[log_n_total], D.q);
+        k.ninv_w = split(D.ninv_w[log_n_total], D.q);
+        k.pb = pb; k.prefix = prefix;
+        return k;
+    }
+    // w y mod q, unreduced: < 2^(B+3) for any y
+    static __device__ __forceinline__ u64 mul_raw(u64 y, const uint4 &w, const DsK &m) {
+        const unsigned y0 = (unsigned)y, y1 = (unsigned)(y >> 32);
+        const u64 s1 = (u64)w.y * y0 + (u64)w.w * y1;
+        const u64 s0 = (u64)w.x * y0 + (u64)w.z * y1;
+        const u64 v = (u64)(unsigned)s1 * m.pw + s0;
+        return (u64)(unsigned)(s1 >> 32) * m.c2 + v;
+    }
+    // x mod~ q: < 2^B + (x >> B) c
+    static __device__ __forceinline__ u64 fold1(u64 x, const DsK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
+    static __device__ __forceinline__ u64 mul(u64 y, const uint4 &w, const DsK &m) { return fold1(mul_raw(y, w, m), m); }  // < q + 9c
+    // Forward butterfly: the multiplicand may be ANY 64-bit value, the product comes back below q + 9c, so a value grows by at
+    // most 2q per layer and only the sums must stay below 2^64: (2^(64-B) - 2) / 2 layers between two folds (7 at 60 bits).
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &w, const K &k) {
+        const u64 t = mul(Y, w, k.m);
+        const u64 x = X;
+        X = x + t;
+        Y = x + k.m.q2 - t;
+    }
+    static constexpr int CT_LAYERS = 64;                      // no fold tied to a network's own layer count ...
+    static constexpr bool PASS_FOLD = false;                  // ... nor to pass boundaries:
+    static constexpr int CT_SPAN = B >= 64 - 2 ? 1 : (((1 << (64 - B)) - 2) / 2 > 64 ? 64 : ((1 << (64 - B)) - 2) / 2);
+    static __device__ constexpr bool ct_fold_at(int layer) { return layer > 0 && layer % CT_SPAN == 0; }  // before this layer of the transform
+    template <int PH>
+    static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &w, const K &k) {
+        const u64 s = X + Y;
+        const u64 d = X + (PH ? k.m.q4 : k.m.q2) - Y;
+        X = s;
+        Y = mul(d, w, k.m);
+    }
+    static constexpr bool GS_FOLDS = true;
+    static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
+        const u64 s = X + Y, d = X + k.m.q4 - Y;
+        X = csub(mul(s, k.ninv, k.m), k.m.q);
+        Y = csub(mul(d, k.ninv_w, k.m), k.m.q);
+    }
+    static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const TwReg &w, const K &k) {
+        const u64 s = X + Y, d = X + k.m.q4 - Y;
+        X = csub(fold1(s, k.m), k.m.q);
+        Y = csub(mul(d, w, k.m), k.m.q);
+    }
+    static __device__ __forceinline__ u64 gs_fold(u64 x, const K &k) { return fold1(x, k.m); }
+    static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }
+    static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
+    static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(mul(x, k.ninv, k.m), k.m.q); }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -311,7 +417,7 @@ __device__ __forceinline__ void tw_load(typename A::TwRaw (&raw)[NTW], int top, 
 template <class A, class U, int NTW, int E>
 __device__ __forceinline__ void ct_apply(typename A::Elem (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
     // lazy policies bound how many layers may run between two folds (multiplicands must stay below 2^63)
-    if constexpr (U::l > 0 && U::l % A::CT_LAYERS == 0) {
+    if constexpr ((U::l > 0 && U::l % A::CT_LAYERS == 0) || A::ct_fold_at(U::L0 + U::l)) {
 #pragma unroll
         for (int rr = 0; rr < U::NREP; ++rr)
 #pragma unroll

@@ -28,6 +28,8 @@ struct Arith30 {
     static constexpr int PREFETCH = 0;
     static constexpr bool GS_FOLDS = false;
     static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
+    static constexpr bool PASS_FOLD = false;
+    static __device__ constexpr bool ct_fold_at(int) { return false; }
     struct K {
         unsigned p, p2;
         const FHE_GLOBAL uint2 *tw, *twi;

@@ -292,6 +292,13 @@ int fhe_external_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, 
     return gadget_entry(ctx, rgsw, index, true, false, 1, ct_a, ct_b, batch, mem, stream);
 }
 
+// scheme/fhew/src/rgsw.rs:130-150: one external product of rgsw[index] per RLWE row of each right-hand RGSW ciphertext
+int fhe_rgsw_internal_product(const fhe_ctx *ctx, const fhe_key *rgsw, size_t index, uint64_t *ct1_a, uint64_t *ct1_b, size_t count,
+                              fhe_mem mem, void *stream) {
+    if (!rgsw || rgsw->rows_per_ct != 2 * rgsw->d) return FHE_ERR_INVALID;
+    return gadget_entry(ctx, rgsw, index, true, false, 1, ct1_a, ct1_b, count * 2 * (size_t)rgsw->d, mem, stream);
+}
+
 int fhe_rlwe_key_switch(const fhe_ctx *ctx, const fhe_key *ksk, size_t index, uint64_t *ct_a, uint64_t *ct_b, size_t batch,
                         fhe_mem mem, void *stream) {
     return gadget_entry(ctx, ksk, index, false, false, 1, ct_a, ct_b, batch, mem, stream);

@@ -219,19 +219,22 @@ __device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, u64 *lds) {
     XCHG_PRIO_DOWN();
 }
 
-// Diagnostic build only (tools/ntt_lab.hip -DNTT14_STAMPS): wave 0 of each workgroup records s_memtime at phase boundaries
+// Diagnostic build only (tools/ntt_lab2.hip -DNTT14_STAMPS): wave 0 of each workgroup keeps s_memtime values of its phase
+// boundaries in SGPRs and writes them out when the transform is done (nothing is stored, and no vector-memory wait is added,
+// inside the transform)
 #ifdef NTT14_STAMPS
 __device__ unsigned long long g_stamps[4096][16];
-#define STAMP(i)                                                                                       \
-    do {                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        unsigned long long t_;                                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x][i] = t_;                       \
+#define STAMP_DECL unsigned long long stamps_[10]
+#define STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps_[i])::"memory")
+#define STAMP_FLUSH()                                                                       \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                          \
+            for (int i_ = 0; i_ < 10; ++i_) g_stamps[blockIdx.x][i_] = stamps_[i_];        \
     } while (0)
 #else
+#define STAMP_DECL
 #define STAMP(i)
+#define STAMP_FLUSH()
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -280,14 +283,12 @@ __device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typena
     u64 x[32];
     typename A::TwRaw ta[8], tb[8];
     const int t1 = t >> 5, t2 = t >> 1;  // block prefixes of passes 1 and 2; pass 3: (s3 << 9) | t
+    STAMP_DECL;
     STAMP(0);
     if constexpr (ahead<A, P0<0>>()) tw_load<A, false, P0<0>>(ta, 0, k);
     // pass 0: layers 0..3
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = g[((r & 15) << 10) | ((r >> 4) << 9) | t];
-#ifdef NTT14_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     STAMP(1);
     fstep<A, P0<0>, P0<1>>(x, ta, tb, 0, 0, k);
     fstep<A, P0<1>, P0<2>>(x, tb, ta, 0, 0, k);
@@ -297,8 +298,10 @@ __device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typena
     xchg_01(x, t, lds);
     STAMP(3);
     // pass 1: layers 4..7, block prefix = bits 13..10
+    if constexpr (A::PASS_FOLD) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
     fstep<A, P1<0>, P1<1>>(x, ta, tb, t1, t1, k);
     fstep<A, P1<1>, P1<2>>(x, tb, ta, t1, t1, k);
     fstep<A, P1<2>, P1<3>>(x, ta, tb, t1, t1, k);
@@ -307,8 +310,10 @@ __device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typena
     xchg_12(x, t, lds);
     STAMP(5);
     // pass 2: layers 8..11, block prefix = bits 13..6
+    if constexpr (A::PASS_FOLD) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
     fstep<A, P2<0>, P2<1>>(x, ta, tb, t2, t2, k);
     fstep<A, P2<1>, P2<2>>(x, tb, ta, t2, t2, k);
     fstep<A, P2<2>, P2<3>>(x, ta, tb, t2, t2, k);
@@ -317,8 +322,10 @@ __device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typena
     xchg_23(x, t, lds);
     STAMP(7);
     // pass 3: layers 12..13, block prefix = bits 13..2 = (s3 << 9) | t
+    if constexpr (A::PASS_FOLD) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
     fstep<A, P3<0, 0>, P3<1, 0>>(x, ta, tb, t, t, k);
     fstep<A, P3<1, 0>, P3<0, 1>>(x, tb, ta, t, t, k);
     fstep<A, P3<0, 1>, P3<1, 1>>(x, ta, tb, t, t, k);
@@ -333,10 +340,8 @@ __device__ __forceinline__ void ntt14_fwd_body(u64 *__restrict__ g, const typena
         dst[0] = lo;
         dst[1] = hi;
     }
-#ifdef NTT14_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     STAMP(9);
+    STAMP_FLUSH();
 }
 
 // PFX = false: a whole 2^14 ring (pb = 0): the block prefix and the table offset are compile-time zeros, which takes the

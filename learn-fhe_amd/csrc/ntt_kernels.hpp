@@ -106,7 +106,7 @@ __device__ __forceinline__ void fwd_run(typename A::Elem (&x)[1 << LOG_E], int t
     // butterflies; lazy values are folded back at a pass boundary only when the policy's reduction-free budget (CT_LAYERS) is
     // smaller than the whole transform: 54-bit pseudo-Mersenne moduli run all log2 N <= 13 layers without a single fold
     // (values < (2 log2 N + 1) q < 2^59), 60-bit ones fold at every boundary
-    if constexpr (!first && A::CT_LAYERS < LOG_N) {
+    if constexpr (!first && A::PASS_FOLD && A::CT_LAYERS < LOG_N) {
 #pragma unroll
         for (int r = 0; r < E; ++r) x[r] = A::fold(x[r], k);
     }

@@ -145,6 +145,13 @@ class GadgetKey:
         pb, _, _, _ = _buf(ct_b)
         L.check(L.lib().fhe_external_product(self.ctx.handle, self._h, index, pa, pb, cnt // self.n, mem, st), "fhe_external_product")
 
+    def internal_product_(self, index, ct1_a, ct1_b):
+        """scheme/fhew/src/rgsw.rs:130-150 with ct0 = this key's entry `index`; ct1_a / ct1_b: [count][2d][n], in place."""
+        pa, cnt, mem, st = _buf(ct1_a)
+        pb, _, _, _ = _buf(ct1_b)
+        L.check(L.lib().fhe_rgsw_internal_product(self.ctx.handle, self._h, index, pa, pb, cnt // (2 * self.d * self.n), mem, st),
+                "fhe_rgsw_internal_product")
+
     def key_switch_(self, index, ct_a, ct_b):
         """scheme/fhew/src/rlwe.rs:177-186."""
         pa, cnt, mem, st = _buf(ct_a)

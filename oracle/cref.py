@@ -231,3 +231,85 @@ def ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a):
 
 def num_threads():
     return lib().ref_num_threads()
+
+
+# ---- TFHE torus path (row T): exact product = the checker; fft64 = the reference's floating-point algorithm (CPU baseline) ----
+
+def torus_mul_exact(a, b):
+    a, b = _arr(a), _arr(b)
+    c = np.zeros_like(a)
+    lib().ref_torus_mul_exact(_p(a), _p(b), _p(c), C.c_size_t(a.size))
+    return c
+
+
+def torus_mul_fft64(a, b):
+    a, b = _arr(a).copy(), _arr(b)
+    lib().ref_torus_mul_fft64(_p(a), _p(b), C.c_size_t(a.size))
+    return a
+
+
+def torus_monomial_mul(a, k):
+    a = _arr(a)
+    out = np.zeros_like(a)
+    lib().ref_torus_monomial_mul(C.c_int64(k), _p(a), _p(out), C.c_size_t(a.size))
+    return out
+
+
+def torus_decompose(log_b, d, a):
+    a = _arr(a)
+    out = np.zeros((d, a.size), dtype=np.uint64)
+    lib().ref_torus_decompose(log_b, d, _p(a), C.c_size_t(a.size), _p(out))
+    return out
+
+
+def tggsw_external_product(log_b, d, rows_a, rows_b, ct_a, ct_b, fft=False):
+    """rows_*: [2d][n] -> (a', b')"""
+    rows_a, rows_b, ct_a, ct_b = _arr(rows_a), _arr(rows_b), _arr(ct_a).copy(), _arr(ct_b).copy()
+    rc = lib().ref_tggsw_external_product(log_b, d, _p(rows_a), _p(rows_b), _p(ct_a), _p(ct_b), C.c_size_t(ct_a.size), int(fft))
+    assert rc == 0
+    return ct_a, ct_b
+
+
+def tfhe_mod_switch(values, big_n):
+    v = _arr(values)
+    out = np.zeros_like(v)
+    lib().ref_tfhe_mod_switch(_p(v), _p(out), C.c_size_t(v.size), C.c_size_t(big_n))
+    return out
+
+
+def tfhe_blind_rotate(log_b, d, brk_a, brk_b, v, a_tilde, b_tilde, threads=1, fft=False):
+    """brk_*: [n_lwe][2d][n]; a_tilde: [batch][n_lwe]; b_tilde: [batch] -> (acc_a, acc_b) each [batch][n]"""
+    brk_a, brk_b, v, a_tilde, b_tilde = _arr(brk_a), _arr(brk_b), _arr(v), _arr(a_tilde), _arr(b_tilde)
+    n, batch, n_lwe = v.size, b_tilde.size, brk_a.shape[0]
+    oa, ob = np.zeros((batch, n), dtype=np.uint64), np.zeros((batch, n), dtype=np.uint64)
+    rc = lib().ref_tfhe_blind_rotate(log_b, d, _p(brk_a), _p(brk_b), C.c_size_t(n_lwe), _p(v), _p(a_tilde), _p(b_tilde), _p(oa), _p(ob),
+                                     C.c_size_t(n), C.c_size_t(batch), threads, int(fft))
+    assert rc == 0
+    return oa, ob
+
+
+def tglwe_sample_extract(ct_a, ct_b, i):
+    ct_a, ct_b = _arr(ct_a), _arr(ct_b)
+    la, lb = np.zeros_like(ct_a), C.c_uint64()
+    lib().ref_tglwe_sample_extract(_p(ct_a), _p(ct_b), C.c_size_t(ct_a.size), C.c_size_t(i), _p(la), C.byref(lb))
+    return la, lb.value
+
+
+def tlwe_key_switch(log_b, d, ksk_a, ksk_b, ct_a, ct_b):
+    ksk_a, ksk_b, ct_a = _arr(ksk_a), _arr(ksk_b), _arr(ct_a)
+    n_in, n_out = ct_a.size, ksk_a.shape[-1]
+    oa, ob = np.zeros(n_out, dtype=np.uint64), C.c_uint64()
+    lib().ref_tlwe_key_switch(log_b, d, _p(ksk_a), _p(ksk_b), _p(ct_a), C.c_uint64(ct_b), C.c_size_t(n_in), C.c_size_t(n_out), _p(oa),
+                              C.byref(ob))
+    return oa, ob.value
+
+
+def tfhe_bootstrap(log_b, d, ks_log_b, ks_d, brk_a, brk_b, ksk_a, ksk_b, v, lwe_a, lwe_b, threads=1, fft=False):
+    """tfhe/bootstrapping.rs:78-82 on a batch: lwe_a [batch][n_lwe], lwe_b [batch] -> (a [batch][n_lwe], b [batch])"""
+    brk_a, brk_b, ksk_a, ksk_b, v, lwe_a, lwe_b = map(_arr, (brk_a, brk_b, ksk_a, ksk_b, v, lwe_a, lwe_b))
+    n, batch, n_lwe = v.size, lwe_b.size, brk_a.shape[0]
+    oa, ob = np.zeros((batch, n_lwe), dtype=np.uint64), np.zeros(batch, dtype=np.uint64)
+    rc = lib().ref_tfhe_bootstrap(log_b, d, ks_log_b, ks_d, _p(brk_a), _p(brk_b), _p(ksk_a), _p(ksk_b), C.c_size_t(n_lwe), _p(v), _p(lwe_a),
+                                  _p(lwe_b), _p(oa), _p(ob), C.c_size_t(n), C.c_size_t(batch), threads, int(fft))
+    assert rc == 0
+    return oa, ob

@@ -124,7 +124,19 @@ typedef struct {
 static ref_twiddle g_tw[MAX_TW];
 static int g_ntw = 0;
 
-static const ref_twiddle *twiddle(u64 q) { /* fft/zq.rs:49-56: per-modulus cache */
+static const ref_twiddle *twiddle_fill(u64 q);
+static const ref_twiddle *twiddle(u64 q) { /* fft/zq.rs:49-56: per-modulus cache (the reference guards it with a Mutex) */
+    int n;
+#pragma omp atomic read
+    n = g_ntw;
+    for (int i = 0; i < n; i++)
+        if (g_tw[i].q == q) return &g_tw[i];
+    const ref_twiddle *t;
+#pragma omp critical(ref_twiddle_cache)
+    t = twiddle_fill(q);
+    return t;
+}
+static const ref_twiddle *twiddle_fill(u64 q) { /* inside the critical section: look again, then build */
     for (int i = 0; i < g_ntw; i++)
         if (g_tw[i].q == q) return &g_tw[i];
     if (!ref_is_prime(q) || g_ntw == MAX_TW) return NULL;
@@ -141,7 +153,8 @@ static const ref_twiddle *twiddle(u64 q) { /* fft/zq.rs:49-56: per-modulus cache
     for (size_t i = 0; i < t->len; i++) t->twi[i] = zq_inv(q, t->tw[i]);
     bit_reverse(t->tw, t->len);
     bit_reverse(t->twi, t->len);
-    g_ntw++;
+#pragma omp atomic update
+    g_ntw++; /* published last: readers outside the critical section only see complete entries */
     return t;
 }
 
@@ -554,6 +567,261 @@ int ref_ckks_key_switch(const u64 *qs, int L, const u64 *ps, int K, const u64 *k
             }
     free(ext);
     return rc;
+}
+
+/* ==== TFHE torus path, k = 1 ======================================
+ * Two products over Z_{2^64}[X]/(X^N+1):
+ *   exact  -- wrapping u64 schoolbook == the signed-integer negacyclic product mod 2^64 (two's complement): the value
+ *             row T's acceptance rule (ii) measures distances to; what the GPU path must equal bit for bit;
+ *   fft64  -- the reference's own algorithm restated (util/src/ring/fft/c64.rs:11-108, util/src/ring/fft.rs:9-35):
+ *             twist by cis(pi i / N), cyclic f64 FFT of size N/2, pointwise, inverse, untwist, f64_mod_u64.  Its low
+ *             bits carry rounding noise (libm cis), so it is NOT a bit-exact checker: it is the CPU baseline
+ *             (cpu_baseline.kind = "port") and the subject of the tolerance test against `exact`. */
+void ref_torus_mul_exact(const u64 *a, const u64 *b, u64 *c, size_t n) { /* ring.rs:421-440 on T64 (torus.rs:48-100) */
+    for (size_t k = 0; k < n; k++) c[k] = 0;
+    for (size_t i = 0; i < n; i++) {
+        const u64 x = a[i];
+        if (!x) continue;
+        for (size_t j = 0; j < n - i; j++) c[i + j] += x * b[j];
+        for (size_t j = n - i; j < n; j++) c[i + j - n] -= x * b[j];
+    }
+}
+
+void ref_torus_monomial_mul(int64_t k, const u64 *in, u64 *out, size_t n) { /* ring.rs:299-313, 380-406 on Rt */
+    const int64_t two_n = 2 * (int64_t)n;
+    const size_t i = (size_t)(((k % two_n) + two_n) % two_n), r = i % n;
+    for (size_t j = 0; j < n; j++) out[(j + r) % n] = in[j]; /* rotate_right(r) */
+    if (i < n) for (size_t j = 0; j < i; j++) out[j] = 0 - out[j];
+    else for (size_t j = i - n; j < n; j++) out[j] = 0 - out[j];
+}
+
+/* decompose.rs:66-81 (new), 114-135: out digit-major [d][n] */
+void ref_torus_decompose(int log_b, int d, const u64 *in, size_t n, u64 *out) {
+    const int rb = 64 - log_b * d > 0 ? 64 - log_b * d : 0;
+    const u64 mask = (log_b >= 64) ? ~(u64)0 : (((u64)1 << log_b) - 1);
+    for (size_t i = 0; i < n; i++) {
+        u64 v = in[i];
+        if (rb) v = (v + (((u64)1 << rb) >> 1)) >> rb; /* rounding_shr, 115-118 (wrapping add) */
+        for (int j = 0; j < d; j++) {
+            const u64 limb = v & mask;
+            v = log_b >= 64 ? 0 : v >> log_b;
+            const u64 carry = (((limb - 1) | v) & limb) >> (log_b - 1);
+            v += carry;
+            out[(size_t)j * n + i] = limb - (carry << log_b);
+        }
+    }
+}
+
+/* c64.rs:69-85 */
+static inline u64 f64_mod_u64(double v) {
+    u64 bits;
+    memcpy(&bits, &v, 8);
+    const u64 sign = bits >> 63, exponent = (bits >> 52) & 0x7ff, mantissa = (bits << 11) | 0x8000000000000000ull;
+    const int64_t shift = 1086 - (int64_t)exponent;
+    u64 value;
+    if (shift >= -63 && shift <= 0) value = mantissa << (-shift);
+    else if (shift >= 1 && shift <= 64) value = ((shift - 1 >= 64 ? 0 : (mantissa >> (shift - 1))) + 1) >> 1;
+    else value = 0;
+    return sign ? 0 - value : value;
+}
+
+typedef struct { double re, im; } c64;
+static inline c64 c_mul(c64 a, c64 b) { c64 r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; return r; }
+static inline c64 c_add(c64 a, c64 b) { c64 r = {a.re + b.re, a.im + b.im}; return r; }
+static inline c64 c_sub(c64 a, c64 b) { c64 r = {a.re - b.re, a.im - b.im}; return r; }
+
+typedef struct { size_t n; c64 *tw, *twi, *tw_bo, *twi_bo; } ref_tw64; /* c64.rs:88-108: [normal, inverse, both bit-reversed] */
+static ref_tw64 g_tw64 = {0, 0, 0, 0, 0};
+static const ref_tw64 *twiddle64(size_t n) {
+    if (g_tw64.n >= n) return &g_tw64;
+    free(g_tw64.tw); free(g_tw64.twi); free(g_tw64.tw_bo); free(g_tw64.twi_bo);
+    g_tw64.n = n;
+    g_tw64.tw = malloc(n * sizeof(c64)); g_tw64.twi = malloc(n * sizeof(c64));
+    g_tw64.tw_bo = malloc(n * sizeof(c64)); g_tw64.twi_bo = malloc(n * sizeof(c64));
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    for (size_t i = 0; i < n; i++) {
+        const double th = ((double)i * M_PI) / (double)n;
+        g_tw64.tw[i].re = cos(th); g_tw64.tw[i].im = sin(th);
+        g_tw64.twi[i].re = g_tw64.tw[i].re; g_tw64.twi[i].im = -g_tw64.tw[i].im;
+    }
+    for (size_t i = 0; i < n; i++) {
+        size_t r = 0;
+        for (int b = 0; b < lg; b++) r |= ((i >> b) & 1) << (lg - 1 - b);
+        if (n <= 2) r = i; /* misc.rs:29-42: no-op for len <= 2 */
+        g_tw64.tw_bo[i] = g_tw64.tw[r]; g_tw64.twi_bo[i] = g_tw64.twi[r];
+    }
+    return &g_tw64;
+}
+/* must be called (single-threaded) before a threaded region uses the f64 path */
+void ref_torus_fft64_prepare(size_t n) { (void)twiddle64(n); }
+
+static void fft64_fwd(c64 *a, size_t len, const c64 *tw_bo) { /* fft.rs:9-17 */
+    int lg = 0;
+    while (((size_t)1 << lg) < len) lg++;
+    for (int layer = lg - 1; layer >= 0; layer--) {
+        const size_t size = (size_t)1 << layer;
+        for (size_t ch = 0; ch * 2 * size < len; ch++) {
+            const c64 t = tw_bo[ch];
+            c64 *x = a + ch * 2 * size, *y = x + size;
+            for (size_t k = 0; k < size; k++) { const c64 tb = c_mul(t, y[k]); const c64 u = x[k]; x[k] = c_add(u, tb); y[k] = c_sub(u, tb); }
+        }
+    }
+}
+static void fft64_inv(c64 *a, size_t len, const c64 *twi_bo) { /* fft.rs:21-35 */
+    int lg = 0;
+    while (((size_t)1 << lg) < len) lg++;
+    for (int layer = 0; layer < lg; layer++) {
+        const size_t size = (size_t)1 << layer;
+        for (size_t ch = 0; ch * 2 * size < len; ch++) {
+            const c64 t = twi_bo[ch];
+            c64 *x = a + ch * 2 * size, *y = x + size;
+            for (size_t k = 0; k < size; k++) { const c64 u = x[k], v = y[k]; x[k] = c_add(u, v); y[k] = c_mul(c_sub(u, v), t); }
+        }
+    }
+    const double n_inv = 1.0 / (double)len;
+    for (size_t k = 0; k < len; k++) { a[k].re *= n_inv; a[k].im *= n_inv; }
+}
+static void to_c64_twisted(const u64 *a, size_t n, const ref_tw64 *T, c64 *out) { /* c64.rs:19-29 */
+    const size_t step = T->n / n;
+    for (size_t i = 0; i < n / 2; i++) {
+        const c64 v = {(double)(int64_t)a[i], (double)(int64_t)a[n / 2 + i]};
+        out[i] = c_mul(v, T->tw[i * step]);
+    }
+}
+/* a <- a * b, the reference's floating-point product (c64.rs:11-17, 43-56); scratch: 2 * (n/2) c64 */
+static void torus_mul_fft64_ws(u64 *a, const u64 *b, size_t n, c64 *ws) {
+    if (n == 1) { a[0] *= b[0]; return; }
+    const ref_tw64 *T = twiddle64(n);
+    c64 *ca = ws, *cb = ws + n / 2;
+    to_c64_twisted(a, n, T, ca);
+    to_c64_twisted(b, n, T, cb);
+    fft64_fwd(ca, n / 2, T->tw_bo);
+    fft64_fwd(cb, n / 2, T->tw_bo);
+    for (size_t i = 0; i < n / 2; i++) ca[i] = c_mul(ca[i], cb[i]);
+    fft64_inv(ca, n / 2, T->twi_bo);
+    const size_t step = T->n / n;
+    for (size_t i = 0; i < n / 2; i++) { /* c64.rs:31-41 */
+        const c64 c = c_mul(ca[i], T->twi[i * step]);
+        a[i] = f64_mod_u64(c.re);
+        a[n / 2 + i] = f64_mod_u64(c.im);
+    }
+}
+void ref_torus_mul_fft64(u64 *a, const u64 *b, size_t n) {
+    c64 *ws = malloc((n ? n : 1) * sizeof(c64));
+    torus_mul_fft64_ws(a, b, n, ws);
+    free(ws);
+}
+
+/* tggsw.rs:100-112, k = 1: limbs = decompose(a) ++ decompose(b); a' = sum rows_a[l] * limb_l, b' = sum rows_b[l] * limb_l
+ * (key polynomial is the lhs of each product).  rows_*: [2d][n].  In place on (ct_a, ct_b).  fft != 0: reference's f64 product. */
+static void tggsw_ext_ws(int log_b, int d, const u64 *rows_a, const u64 *rows_b, u64 *ct_a, u64 *ct_b, size_t n, int fft, u64 *ws) {
+    u64 *limbs = ws, *oa = ws + (size_t)2 * d * n, *ob = oa + n, *tmp = ob + n;
+    c64 *cws = (c64 *)(tmp + n);
+    ref_torus_decompose(log_b, d, ct_a, n, limbs);
+    ref_torus_decompose(log_b, d, ct_b, n, limbs + (size_t)d * n);
+    memset(oa, 0, 2 * n * sizeof(u64));
+    for (int l = 0; l < 2 * d; l++) {
+        const u64 *limb = limbs + (size_t)l * n;
+        for (int c = 0; c < 2; c++) {
+            const u64 *row = (c ? rows_b : rows_a) + (size_t)l * n;
+            u64 *o = c ? ob : oa;
+            if (fft) { memcpy(tmp, row, n * sizeof(u64)); torus_mul_fft64_ws(tmp, limb, n, cws); }
+            else ref_torus_mul_exact(row, limb, tmp, n);
+            for (size_t i = 0; i < n; i++) o[i] += tmp[i];
+        }
+    }
+    memcpy(ct_a, oa, n * sizeof(u64));
+    memcpy(ct_b, ob, n * sizeof(u64));
+}
+static size_t tggsw_ws_words(int d, size_t n) { return (size_t)2 * d * n + 3 * n + 2 * n /* c64 scratch: n c64 = 2n words */; }
+
+int ref_tggsw_external_product(int log_b, int d, const u64 *rows_a, const u64 *rows_b, u64 *ct_a, u64 *ct_b, size_t n, int fft) {
+    if (log_b < 1 || d < 1 || log_b * d > 64 + log_b - 1) return 1;
+    u64 *ws = malloc(tggsw_ws_words(d, n) * sizeof(u64));
+    if (fft) ref_torus_fft64_prepare(n);
+    tggsw_ext_ws(log_b, d, rows_a, rows_b, ct_a, ct_b, n, fft, ws);
+    free(ws);
+    return 0;
+}
+
+/* tfhe/bootstrapping.rs:99-104 */
+void ref_tfhe_mod_switch(const u64 *in, u64 *out, size_t count, size_t big_n) {
+    int lg = 0;
+    while (((size_t)1 << lg) < 2 * big_n) lg++;
+    const int bits = 64 - lg;
+    for (size_t i = 0; i < count; i++) out[i] = (in[i] + (((u64)1 << bits) >> 1)) >> bits;
+}
+
+/* tfhe/bootstrapping.rs:84-96, k = 1: acc = (0, v).rotate(-b); fold cmux(brk_i, acc, acc.rotate(a_i)) (tggsw.rs:114-121).
+ * brk_a / brk_b: [n_lwe][2d][n]; a_tilde: [batch][n_lwe] (already mod-switched); out: [batch][n] each. */
+int ref_tfhe_blind_rotate(int log_b, int d, const u64 *brk_a, const u64 *brk_b, size_t n_lwe, const u64 *v, const u64 *a_tilde,
+                          const u64 *b_tilde, u64 *out_a, u64 *out_b, size_t n, size_t batch, int threads, int fft) {
+    if (fft) ref_torus_fft64_prepare(n);
+    (void)threads;
+#pragma omp parallel for schedule(dynamic) num_threads(threads > 0 ? threads : 1)
+    for (size_t c = 0; c < batch; c++) {
+        u64 *ws = malloc((tggsw_ws_words(d, n) + 4 * n) * sizeof(u64));
+        u64 *acc_a = ws, *acc_b = ws + n, *da = ws + 2 * n, *db = ws + 3 * n, *ext = ws + 4 * n;
+        memset(acc_a, 0, n * sizeof(u64));
+        ref_torus_monomial_mul(-(int64_t)b_tilde[c], v, acc_b, n);
+        for (size_t i = 0; i < n_lwe; i++) {
+            const int64_t ai = (int64_t)a_tilde[c * n_lwe + i];
+            ref_torus_monomial_mul(ai, acc_a, da, n);
+            ref_torus_monomial_mul(ai, acc_b, db, n);
+            for (size_t k = 0; k < n; k++) { da[k] -= acc_a[k]; db[k] -= acc_b[k]; }
+            tggsw_ext_ws(log_b, d, brk_a + i * 2 * d * n, brk_b + i * 2 * d * n, da, db, n, fft, ext);
+            for (size_t k = 0; k < n; k++) { acc_a[k] += da[k]; acc_b[k] += db[k]; }
+        }
+        memcpy(out_a + c * n, acc_a, n * sizeof(u64));
+        memcpy(out_b + c * n, acc_b, n * sizeof(u64));
+        free(ws);
+    }
+    return 0;
+}
+
+/* tglwe.rs:115-127 (k = 1) */
+void ref_tglwe_sample_extract(const u64 *ct_a, const u64 *ct_b, size_t n, size_t i, u64 *lwe_a, u64 *lwe_b) {
+    for (size_t j = 0; j <= i; j++) lwe_a[j] = ct_a[i - j];
+    for (size_t j = i + 1; j < n; j++) lwe_a[j] = 0 - ct_a[n + i - j];
+    *lwe_b = ct_b[i];
+}
+
+/* tlwe.rs:144-153: limbs digit-major (decompose(a).flatten()); ksk_a: [n_in * d][n_out], ksk_b: [n_in * d] */
+void ref_tlwe_key_switch(int log_b, int d, const u64 *ksk_a, const u64 *ksk_b, const u64 *ct_a, u64 ct_b, size_t n_in, size_t n_out,
+                         u64 *out_a, u64 *out_b) {
+    u64 *limbs = malloc((size_t)d * n_in * sizeof(u64));
+    ref_torus_decompose(log_b, d, ct_a, n_in, limbs);
+    memset(out_a, 0, n_out * sizeof(u64));
+    u64 b = 0;
+    for (size_t r = 0; r < (size_t)d * n_in; r++) {
+        const u64 l = limbs[r];
+        const u64 *row = ksk_a + r * n_out;
+        for (size_t k = 0; k < n_out; k++) out_a[k] += row[k] * l;
+        b += ksk_b[r] * l;
+    }
+    *out_b = b + ct_b;
+    free(limbs);
+}
+
+/* tfhe/bootstrapping.rs:78-82: blind rotate -> sample_extract(0) -> key switch, for a batch of TLWE ciphertexts (a: [batch][n_lwe]) */
+int ref_tfhe_bootstrap(int log_b, int d, int ks_log_b, int ks_d, const u64 *brk_a, const u64 *brk_b, const u64 *ksk_a, const u64 *ksk_b,
+                       size_t n_lwe, const u64 *v, const u64 *lwe_a, const u64 *lwe_b, u64 *out_a, u64 *out_b, size_t n, size_t batch,
+                       int threads, int fft) {
+    u64 *at = malloc(batch * n_lwe * sizeof(u64)), *bt = malloc(batch * sizeof(u64));
+    u64 *ra = malloc(batch * n * sizeof(u64)), *rb = malloc(batch * n * sizeof(u64));
+    ref_tfhe_mod_switch(lwe_a, at, batch * n_lwe, n);
+    ref_tfhe_mod_switch(lwe_b, bt, batch, n);
+    ref_tfhe_blind_rotate(log_b, d, brk_a, brk_b, n_lwe, v, at, bt, ra, rb, n, batch, threads, fft);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1)
+    for (size_t c = 0; c < batch; c++) {
+        u64 *ea = malloc(n * sizeof(u64)), eb;
+        ref_tglwe_sample_extract(ra + c * n, rb + c * n, n, 0, ea, &eb);
+        ref_tlwe_key_switch(ks_log_b, ks_d, ksk_a, ksk_b, ea, eb, n, n_lwe, out_a + c * n_lwe, out_b + c);
+        free(ea);
+    }
+    free(at); free(bt); free(ra); free(rb);
+    return 0;
 }
 
 int ref_num_threads(void) {

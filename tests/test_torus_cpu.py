@@ -62,3 +62,73 @@ def test_gate_bootstrap_decode_level_toy():
             oa, ob = P.tlwe_key_switch(ksdec, ksa, ksb, ea, eb)
             mu = ((P.tlwe_phase(z, oa, ob) + (1 << (log_delta - 1))) % P.M64) >> log_delta
             assert mu % p == f(msg) % p
+
+
+# ---- the C restatement of row T (oracle/ref_ring.c) against the Python big-integer restatement ----
+
+def _rows(rnd, count, n):
+    return [[rnd.getrandbits(64) for _ in range(n)] for _ in range(count)]
+
+
+def test_c_oracle_torus_matches_python_oracle():
+    import numpy as np
+    from oracle import cref
+    rnd = random.Random(40)
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    L = lambda x: [int(v) for v in np.asarray(x).ravel()]  # noqa: E731
+    for log_b, d in [(23, 1), (4, 5), (8, 3), (7, 9), (32, 2), (16, 4)]:
+        dec = P.TorusDecomposor(log_b, d)
+        v = [0, 1, P.M64 - 1, 1 << 63, (1 << 63) - 1] + [rnd.getrandbits(64) for _ in range(59)]
+        assert cref.torus_decompose(log_b, d, U(v)).tolist() == dec.decompose(v)
+    for n in (1, 2, 16, 64):
+        a, b = [rnd.getrandbits(64) for _ in range(n)], [rnd.getrandbits(64) for _ in range(n)]
+        assert L(cref.torus_mul_exact(U(a), U(b))) == P.torus_mul_exact(a, b)
+        for k in (0, 1, n - 1, n, n + 1, 2 * n - 1, 2 * n, -1, -n - 3, 5 * n + 2):
+            assert L(cref.torus_monomial_mul(U(a), k)) == P.torus_monomial_mul(a, k)
+    n, n_lwe, log_b, d = 32, 5, 10, 2
+    dec, ksdec = P.TorusDecomposor(log_b, d), P.TorusDecomposor(4, 5)
+    brk = [(_rows(rnd, 2 * d, n), _rows(rnd, 2 * d, n)) for _ in range(n_lwe)]
+    ca, cb = [rnd.getrandbits(64) for _ in range(n)], [rnd.getrandbits(64) for _ in range(n)]
+    ea, eb = cref.tggsw_external_product(log_b, d, U(brk[0][0]), U(brk[0][1]), U(ca), U(cb))
+    assert (L(ea), L(eb)) == P.tggsw_external_product(dec, brk[0][0], brk[0][1], ca, cb)
+    v = [rnd.getrandbits(64) for _ in range(n)]
+    a_raw, b_raw = [[rnd.getrandbits(64) for _ in range(n_lwe)] for _ in range(3)], [rnd.getrandbits(64) for _ in range(3)]
+    a_raw[1][2] = 0
+    at, bt = cref.tfhe_mod_switch(U(a_raw), n), cref.tfhe_mod_switch(U(b_raw), n)
+    assert [L(r) for r in at] == [P.tfhe_mod_switch(r, n) for r in a_raw] and L(bt) == P.tfhe_mod_switch(b_raw, n)
+    oa, ob = cref.tfhe_blind_rotate(log_b, d, U([k[0] for k in brk]), U([k[1] for k in brk]), U(v), at, bt, threads=2)
+    ksa, ksb = _rows(rnd, n * 5, n_lwe), [rnd.getrandbits(64) for _ in range(n * 5)]
+    ga, gb = cref.tfhe_bootstrap(log_b, d, 4, 5, U([k[0] for k in brk]), U([k[1] for k in brk]), U(ksa), U(ksb), U(v), U(a_raw), U(b_raw), threads=2)
+    for i in range(3):
+        acc = P.tfhe_blind_rotate(dec, brk, v, L(at[i]), int(bt[i]))
+        assert L(oa[i]) == acc[0] and L(ob[i]) == acc[1]
+        xa, xb = P.tglwe_sample_extract(acc[0], acc[1], 0)
+        sa, sb = cref.tglwe_sample_extract(oa[i], ob[i], 0)
+        assert (L(sa), sb) == (xa, xb)
+        assert (L(cref.tglwe_sample_extract(oa[i], ob[i], 7)[0]), cref.tglwe_sample_extract(oa[i], ob[i], 7)[1]) == P.tglwe_sample_extract(acc[0], acc[1], 7)
+        ya, yb = P.tlwe_key_switch(ksdec, ksa, ksb, xa, xb)
+        ka, kb = cref.tlwe_key_switch(4, 5, U(ksa), U(ksb), sa, sb)
+        assert (L(ka), kb) == (ya, yb) and (L(ga[i]), int(gb[i])) == (ya, yb)
+
+
+def test_reference_f64_product_is_within_its_own_bound_of_the_exact_one():
+    """util/src/ring/fft/c64.rs:186-208 (`precision`): |fft - schoolbook| <= 2^(64 + log_b + log_n - 53) for n 2^8..2^11 and
+    b 2^12..2^17, re-run on the C restatement of the reference's floating-point product (the CPU baseline) with fixed seeds; and
+    c64.rs:169-184: small operands come out exact.  The GPU path equals the exact product, so it is inside this bound by definition."""
+    import numpy as np
+    from oracle import cref
+    for log_n in range(8, 12):
+        n = 1 << log_n
+        for log_b in range(12, 18):
+            rng = np.random.Generator(np.random.PCG64(log_n * 100 + log_b))
+            a = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+            b = rng.integers(-(1 << log_b) + 1, 1 << log_b, size=n, dtype=np.int64).view(np.uint64)
+            exact, fft = cref.torus_mul_exact(a, b), cref.torus_mul_fft64(a, b)
+            diff = (fft - exact).view(np.int64)
+            bound = 1 << (64 + log_b + log_n - 53)
+            assert int(np.abs(diff).max()) <= bound, (log_n, log_b, int(np.abs(diff).max()), bound)
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n in (2, 16, 256, 1024):
+        a = rng.integers(-(1 << 15), 1 << 15, size=n, dtype=np.int64).view(np.uint64)
+        b = rng.integers(-(1 << 15), 1 << 15, size=n, dtype=np.int64).view(np.uint64)
+        assert np.array_equal(cref.torus_mul_fft64(a, b), cref.torus_mul_exact(a, b))

@@ -252,3 +252,117 @@ def test_external_product_at_the_path_boundary(fhe, torch_cuda, log_b, d):
     for i in range(2):
         ea, eb = P.tggsw_external_product(dec, ra[0], rb[0], ca[i], cb[i])
         assert L(host(a)[i]) == ea and L(host(b)[i]) == eb, (log_b, i)
+
+
+# ---- cfg5's ring, N = 2^10: every instantiation bench.py times, against the exact oracle's C restatement (oracle/ref_ring.c) ----
+
+@pytest.mark.parametrize("log_b,d,path", [(7, 3, "three 30-bit primes (the cfg5 gadget)"), (10, 2, "three 30-bit primes"),
+                                           (23, 1, "two 60-bit primes"), (16, 2, "two 60-bit primes")])
+def test_tggsw_external_product_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, path):
+    """scheme/tfhe/src/tggsw.rs:100-112 at N = 1024 on BOTH prime paths (fhe_tggsw_prepare picks the path from the bound
+    2d N 2^(62 + log_b): (7,3) -> 2^82, (10,2) -> 2^85: 30-bit primes; (23,1) -> 2^97, (16,2) -> 2^91: 60-bit primes),
+    two key entries, a ragged batch with extreme torus values; bit-equal to the exact product"""
+    n, batch, count = 1024, 5, 2
+    rng = np.random.Generator(np.random.PCG64(1000 + log_b))
+    r64 = lambda *shape: rng.integers(0, 1 << 63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)  # noqa: E731
+    ra, rb = r64(count, 2 * d, n), r64(count, 2 * d, n)
+    ra[0, 0, :] = np.uint64(1 << 63)                     # a key row of all -2^63
+    ca, cb = r64(batch, n), r64(batch, n)
+    ca[0, :5] = [0, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, 1]
+    half = 1 << (log_b - 1)
+    cb[1, :] = np.uint64((-sum(half << (64 - log_b * (j + 1)) for j in range(d))) % (1 << 64))  # every digit at its extreme
+    t = fhe.TorusContext()
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+    for idx in range(count):
+        a, b = dev(torch_cuda, ca), dev(torch_cuda, cb)
+        key.external_product_(idx, a, b)
+        ha, hb = host(a), host(b)
+        for i in range(batch):
+            ea, eb = cref.tggsw_external_product(log_b, d, ra[idx], rb[idx], ca[i], cb[i])
+            assert np.array_equal(ha[i], ea) and np.array_equal(hb[i], eb), (path, idx, i)
+
+
+@pytest.mark.parametrize("log_b,d,n_lwe,batch", [(7, 3, 10, 7), (23, 1, 8, 7), (7, 3, 4, 1100), (23, 1, 3, 600)])
+def test_blind_rotate_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, n_lwe, batch):
+    """scheme/tfhe/src/bootstrapping.rs:84-104 at N = 1024 (cfg5's ring): mod switch, the whole CMUX chain, sample extract and the
+    TLWE key switch, bit-equal to the exact oracle on both prime paths; small batches and batches that fill the GPU (every
+    ciphertext of the small ones, a spread sample of the large ones, their first and last included)"""
+    n, ks_log_b, ks_d = 1024, 4, 5
+    rng = np.random.Generator(np.random.PCG64(2000 + log_b + batch))
+    r64 = lambda *shape: rng.integers(0, 1 << 63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)  # noqa: E731
+    bra, brb, v = r64(n_lwe, 2 * d, n), r64(n_lwe, 2 * d, n), r64(n)
+    a_raw, b_raw = r64(batch, n_lwe), r64(batch)
+    a_raw[batch - 1, 1] = 0                               # a rotation by zero: that CMUX short-circuits
+    a_raw[0, 0] = np.uint64((1 << 64) - 1)                # rounds up to 2N = 0 (mod 2N)
+    t = fhe.TorusContext()
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, bra), dev(torch_cuda, brb), n)
+    at = fhe.TorusContext.mod_switch(dev(torch_cuda, a_raw), n)
+    bt = fhe.TorusContext.mod_switch(dev(torch_cuda, b_raw), n)
+    assert np.array_equal(host(at).reshape(batch, n_lwe), cref.tfhe_mod_switch(a_raw, n)) and np.array_equal(host(bt), cref.tfhe_mod_switch(b_raw, n))
+    oa, ob = key.blind_rotate(at, bt, dev(torch_cuda, v))
+    ksa, ksb = r64(n * ks_d, n_lwe), r64(n * ks_d)
+    ea, eb = fhe.tglwe_sample_extract(oa, ob, n, 0)
+    ka, kb = fhe.tlwe_key_switch(ks_log_b, ks_d, dev(torch_cuda, ksa), dev(torch_cuda, ksb), ea, eb, n, n_lwe)
+    pick = list(range(batch)) if batch <= 16 else sorted(set([0, 1, 63, 64, 255, 256, 511, 512, 513, batch - 2, batch - 1] + list(range(7, batch, 97))))
+    ga, gb = cref.tfhe_bootstrap(log_b, d, ks_log_b, ks_d, bra, brb, ksa, ksb, v, a_raw[pick], b_raw[pick], threads=16)
+    ra_, rb_ = cref.tfhe_blind_rotate(log_b, d, bra, brb, v, cref.tfhe_mod_switch(a_raw[pick], n), cref.tfhe_mod_switch(b_raw[pick], n), threads=16)
+    hoa, hob, hka, hkb = host(oa).reshape(batch, n), host(ob).reshape(batch, n), host(ka).reshape(batch, n_lwe), host(kb)
+    for j, i in enumerate(pick):
+        assert np.array_equal(hoa[i], ra_[j]) and np.array_equal(hob[i], rb_[j]), ("blind rotation", i)
+        assert np.array_equal(hka[i], ga[j]) and int(hkb[i]) == int(gb[j]), ("gate output", i)
+
+
+def test_gate_bootstrap_decode_level_n1024(fhe, cref, torch_cuda):
+    """scheme/tfhe/src/bootstrapping.rs:139-165 shaped for cfg5: big_n = 1024, k = 1, base 2^7 x 3 (three 30-bit primes), binary
+    LWE key of 256 bits, key switch (4, 5), log_p 4, padding 1; LUTs identity / double / parity over all 16 messages with a VALID
+    bootstrapping key (encryptions of zero built with the exact GPU product, noise of a few units).  Decode-level equality, and
+    the same ciphertexts bit-equal to the exact oracle's gate."""
+    from oracle import pyref as P
+    rnd = random.Random(12)
+    n, n_lwe, log_p, padding, log_b, d = 1024, 256, 4, 1, 7, 3
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    dec, ksdec = P.TorusDecomposor(log_b, d), P.TorusDecomposor(4, 5)
+    z = [rnd.randint(0, 1) for _ in range(n_lwe)]
+    s = [rnd.randint(0, 1) for _ in range(n)]
+    t = fhe.TorusContext()
+    rows = n_lwe * 2 * d
+    rng = np.random.Generator(np.random.PCG64(6))
+    A = rng.integers(0, 1 << 63, size=(rows, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(rows, n), dtype=np.uint64)
+    S = np.tile(np.array(s, dtype=np.uint64), (rows, 1))
+    dB = dev(torch_cuda, A.copy())
+    t.mul_(dB, dev(torch_cuda, S), 1, n)
+    Bm = host(dB) + rng.integers(0, 5, size=(rows, n), dtype=np.uint64) - np.uint64(2)  # b = a s + e, e in [-2, 2]
+    assert np.array_equal(host(dB)[3], cref.torus_mul_exact(A[3], S[3]))                 # the key material itself is exact
+    ra, rb = A.reshape(n_lwe, 2 * d, n).copy(), Bm.reshape(n_lwe, 2 * d, n).copy()
+    for i, zi in enumerate(z):
+        for j, base in enumerate(dec.bases):  # torus addition wraps
+            ra[i, j, 0] = np.uint64((int(ra[i, j, 0]) + zi * base) % P.M64)
+            rb[i, d + j, 0] = np.uint64((int(rb[i, d + j, 0]) + zi * base) % P.M64)
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+    ksa, ksb = P.tlwe_ksk_gen(ksdec, z, s, rnd, noise=2)
+    ksa, ksb = U(ksa), U(ksb)
+
+    def table(f):
+        m_ = n >> log_p
+        tt = [f(v) % p for v in range(p)]
+        out = [tt[0]] * (m_ // 2)
+        for x in tt[1:]:
+            out += [x] * m_
+        return out + [(-tt[0]) % p] * (m_ // 2)
+
+    for li, f in enumerate((lambda v: v, lambda v: 2 * v, lambda v: v % 2)):
+        v = U([(x << log_delta) % P.M64 for x in table(f)])
+        cts = [P.tlwe_sk_encrypt(z, (m << log_delta) % P.M64, rnd, noise=2) for m in range(p)]
+        a_raw, b_raw = U([c[0] for c in cts]), U([c[1] for c in cts])
+        at = fhe.TorusContext.mod_switch(dev(torch_cuda, a_raw), n)
+        bt = fhe.TorusContext.mod_switch(dev(torch_cuda, b_raw), n)
+        oa, ob = key.blind_rotate(at, bt, dev(torch_cuda, v))
+        ea, eb = fhe.tglwe_sample_extract(oa, ob, n, 0)
+        ka, kb = fhe.tlwe_key_switch(4, 5, dev(torch_cuda, ksa), dev(torch_cuda, ksb), ea, eb, n, n_lwe)
+        hka, hkb = host(ka).reshape(p, n_lwe), host(kb)
+        for m in range(p):
+            mu = ((P.tlwe_phase(z, L(hka[m]), int(hkb[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
+            assert mu % p == f(m) % p, (li, m, mu)
+        if li == 0:  # 4 of the 16 through the exact oracle's whole gate (n_lwe = 256 CMUXes each)
+            ga, gb = cref.tfhe_bootstrap(log_b, d, 4, 5, ra, rb, ksa, ksb, v, a_raw[[0, 5, 10, 15]], b_raw[[0, 5, 10, 15]], threads=16)
+            assert np.array_equal(hka[[0, 5, 10, 15]], ga) and np.array_equal(hkb[[0, 5, 10, 15]], gb)

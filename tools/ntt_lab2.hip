@@ -1,0 +1,143 @@
+// Developer lab 2: A/B of arithmetic policies inside the N = 2^14 kernels (ntt14.hpp), interleaved in one process.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o lab2 tools/ntt_lab2.hip      Run: ./lab2 [batch] [reps]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../learn-fhe_amd/csrc/modmath.hpp"
+#include "../learn-fhe_amd/csrc/ntt_kernels.hpp"
+#include "../learn-fhe_amd/csrc/ntt14.hpp"
+using namespace fhe;
+
+struct DS60p0 : ArithDS<60> { static constexpr int PREFETCH = 0; };
+struct DS60p2 : ArithDS<60> { static constexpr int PREFETCH = 2; };
+struct DS60p8 : ArithDS<60> { static constexpr int PREFETCH = 8; };
+
+int main(int argc, char **argv) {
+    const u64 q = 1152921504606748673ull;
+    const int n = 1 << 14, batch = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int s = __builtin_ctzll(q - 1);
+    u64 g = smallest_nonresidue(q), omega = powmod(g, (q - 1) >> s, q);
+    const int log_cap = s - 1;
+    const size_t cap = size_t(1) << log_cap;
+    u64 psi_inv = invmod(omega, q);
+    std::vector<TwPair> tw(cap), twi(cap);
+    std::vector<u64> pw(cap), pwi(cap);
+    u64 x = 1, y = 1;
+    for (size_t i = 0; i < cap; ++i) { pw[i] = x; pwi[i] = y; x = mulmod(x, omega, q); y = mulmod(y, psi_inv, q); }
+    for (size_t j = 0; j < cap; ++j) {
+        size_t r = bitrev((unsigned)j, log_cap);
+        tw[j] = {pw[r], shoup(pw[r], q)}; twi[j] = {pwi[r], shoup(pwi[r], q)};
+    }
+    ModDesc hd{};
+    hd.q = q; hd.one_s = shoup(1, q);
+    for (int k = 0; k < 20; ++k) { hd.ninv[k] = invmod((u64(1) << k) % q, q); hd.ninv_s[k] = shoup(hd.ninv[k], q);
+                                  hd.ninv_w[k] = mulmod(hd.ninv[k], twi[1].w, q); hd.ninv_w_s[k] = shoup(hd.ninv_w[k], q); }
+    {
+        TwPair *d_tw, *d_twi;
+        hipMalloc(&d_tw, cap * sizeof(TwPair)); hipMalloc(&d_twi, cap * sizeof(TwPair));
+        hipMemcpy(d_tw, tw.data(), cap * sizeof(TwPair), hipMemcpyHostToDevice);
+        hipMemcpy(d_twi, twi.data(), cap * sizeof(TwPair), hipMemcpyHostToDevice);
+        hd.tw = d_tw; hd.twi = d_twi;
+        std::vector<u64> w(cap), wi(cap);
+        std::vector<uint4> wd(cap), wdi(cap);
+        for (size_t j = 0; j < cap; ++j) {
+            w[j] = ArithPM<60>::pack(tw[j].w); wi[j] = ArithPM<60>::pack(twi[j].w);
+            wd[j] = ArithDS<60>::split(tw[j].w, q); wdi[j] = ArithDS<60>::split(twi[j].w, q);
+        }
+        u64 *dw, *dwi; uint4 *dd, *ddi;
+        hipMalloc(&dw, cap * 8); hipMalloc(&dwi, cap * 8); hipMalloc(&dd, cap * 16); hipMalloc(&ddi, cap * 16);
+        hipMemcpy(dw, w.data(), cap * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dwi, wi.data(), cap * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dd, wd.data(), cap * 16, hipMemcpyHostToDevice);
+        hipMemcpy(ddi, wdi.data(), cap * 16, hipMemcpyHostToDevice);
+        hd.tww = dw; hd.twwi = dwi; hd.pm_b = 60; hd.pm_c = (unsigned)((u64(1) << 60) - q);
+        hd.twd = dd; hd.twdi = ddi; hd.ds_pow = 1u << (60 - 31);
+    }
+    ModDesc *d_desc;
+    hipMalloc(&d_desc, sizeof(ModDesc));
+    hipMemcpy(d_desc, &hd, sizeof(ModDesc), hipMemcpyHostToDevice);
+    std::vector<u64> h(size_t(n) * batch);
+    u64 st = 88172645463325252ull;
+    for (auto &v : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = st % q; }
+    // worst-case operands in the first polynomials: all q-1, all zero, alternating
+    for (int i = 0; i < n && batch > 3; ++i) { h[i] = q - 1; h[n + i] = 0; h[2 * n + i] = (i & 1) ? q - 1 : 0; }
+    u64 *d;
+    hipMalloc(&d, h.size() * 8);
+    typedef void (*kern_t)(u64 *, const ModDesc *, unsigned, unsigned, int);
+    struct V { const char *name; kern_t f, i; double sf, si; };
+    V vs[] = {
+        {"PM60 (round-1 product)", ntt14_fwd_kernel<ArithPM<60>, false>, ntt14_inv_kernel<ArithPM<60>, false>, 0, 0},
+        {"DS60 (two-operand split)", ntt14_fwd_kernel<ArithDS<60>, false>, ntt14_inv_kernel<ArithDS<60>, false>, 0, 0},
+        {"DS60, no twiddle prefetch", ntt14_fwd_kernel<DS60p0, false>, ntt14_inv_kernel<DS60p0, false>, 0, 0},
+        {"DS60, prefetch <= 2", ntt14_fwd_kernel<DS60p2, false>, ntt14_inv_kernel<DS60p2, false>, 0, 0},
+        {"DS60, prefetch all", ntt14_fwd_kernel<DS60p8, false>, ntt14_inv_kernel<DS60p8, false>, 0, 0},
+    };
+    std::vector<u64> ref(h.size()), got(h.size());
+    for (auto &v : vs) {
+        hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+        hipFuncSetAttribute((const void *)v.i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        if (&v == &vs[0]) ref = got;
+        size_t badf = 0, badi = 0;
+        for (size_t i = 0; i < h.size(); ++i) badf += got[i] != ref[i];
+        hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < h.size(); ++i) badi += got[i] != h[i];
+        hipError_t e = hipDeviceSynchronize();
+        printf("%-32s forward mismatches vs PM60 %zu, round-trip mismatches %zu (%s)\n", v.name, badf, badi, hipGetErrorString(e));
+    }
+    hipEvent_t e0, e1, e2;
+    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+    // pre-heat: ~100 ms of the first variant
+    for (int r = 0; r < 150; ++r) {
+        hipLaunchKernelGGL(vs[0].f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(vs[0].i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+    }
+    hipDeviceSynchronize();
+    for (int r = 0; r < reps; ++r)
+        for (auto &v : vs) {
+            // 4 back-to-back pairs per sample so that a sample is ~3 ms of steady load
+            float f = 0, i = 0;
+            for (int k = 0; k < 4; ++k) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e1);
+                hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipEventRecord(e2);
+                hipEventSynchronize(e2);
+                float a, b;
+                hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2);
+                f += a; i += b;
+            }
+            v.sf += f / 4; v.si += i / 4;
+        }
+    const double bytes = 16.0 * n * batch;
+    for (auto &v : vs)
+        printf("%-32s fwd %.4f ms %5.0f GB/s (%.3f of 8 TB/s) | inv %.4f ms %5.0f GB/s (%.3f)\n", v.name, v.sf / reps, bytes / (v.sf / reps * 1e-3) / 1e9,
+               bytes / (v.sf / reps * 1e-3) / 8e12, v.si / reps, bytes / (v.si / reps * 1e-3) / 1e9, bytes / (v.si / reps * 1e-3) / 8e12);
+#ifdef NTT14_STAMPS
+    for (int vi = 0; vi < 3; ++vi) {   // where does a workgroup spend its life?
+        auto &v = vs[vi];
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipDeviceSynchronize();
+        static unsigned long long hs[4096][16];
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+        const char *names[] = {"issue loads", "pass0 (+load wait)", "xchg01", "pass1", "xchg12", "pass2", "xchg23", "pass3", "canon+store issue"};
+        double sum[9] = {0}; double life = 0; int cnt = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < batch && b < 4096; ++b) {
+            if (hs[b][9] <= hs[b][0]) continue;
+            for (int p2 = 0; p2 < 9; ++p2) sum[p2] += double(hs[b][p2 + 1] - hs[b][p2]);
+            life += double(hs[b][9] - hs[b][0]); ++cnt;
+            if (hs[b][0] < t0) t0 = hs[b][0];
+            if (hs[b][9] > t1) t1 = hs[b][9];
+        }
+        printf("%s: stamps (s_memtime ticks, avg over %d workgroups; lifetime %.0f; kernel span %llu ticks)\n", v.name, cnt, life / cnt, t1 - t0);
+        for (int p2 = 0; p2 < 9; ++p2) printf("  %-20s %8.0f (%4.1f%%)\n", names[p2], sum[p2] / cnt, 100.0 * sum[p2] / life);
+    }
+#endif
+    return 0;
+}
