@@ -22,6 +22,14 @@ template <class T>
 __device__ __forceinline__ const FHE_GLOBAL T *as_global(const T *p) {
     return (const FHE_GLOBAL T *)p;
 }
+// Twiddle tables are never written while a kernel runs: read through the CONSTANT address space a wave-uniform index becomes a
+// scalar load (SGPRs, lgkmcnt) even when the kernel has stored to global memory before -- a persistent workgroup's second
+// transform, where plain global loads can no longer be proven unclobbered and fall back to 64 lanes loading one address.
+#define FHE_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const FHE_CONST T *as_const(const T *p) {
+    return (const FHE_CONST T *)p;
+}
 
 // non-template kernels defined in headers that several translation units include (each unit uses a subset)
 #define FHE_HEADER_KERNEL static __attribute__((unused)) __global__
@@ -66,12 +74,14 @@ struct ArithShoup {
     }
     // The LAST inverse layer of a whole ring with n^-1 folded in (util/src/ring/fft.rs:59-77: layer 0, then `* n_inv`): the
     // difference branch takes twi[1] n^-1 as its twiddle, only the sum branch still needs a product.  Canonical outputs.
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
         const u64 s = X + Y, d = X - Y + k.q2;
         X = csub(mul_shoup_lazy(s, k.ninv, k.ninv_s, k.q), k.q);
         Y = csub(mul_shoup_lazy(d, k.ninv_w.w, k.ninv_w.ws, k.q), k.q);
     }
     // ... and of a sub-transform (pb > 0: no scaling here): an ordinary butterfly, canonical outputs
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const TwPair &p, const K &k) {
         gs_bfly(X, Y, p.w, p.ws, k.q, k.q2);
         X = csub(X, k.q); Y = csub(Y, k.q);
@@ -92,6 +102,7 @@ struct ArithShoup {
     template <int PH>
     static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &p, const K &k) { gs_bfly(X, Y, p.w, p.ws, k.q, k.q2); }
     static constexpr bool GS_FOLDS = false;
+    static constexpr int GS_SPAN = 0;
     static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
     static constexpr bool PASS_FOLD = false;
     static __device__ constexpr bool ct_fold_at(int) { return false; }
@@ -181,7 +192,7 @@ struct ArithPM {
     static constexpr u64 MASK = (u64(1) << B) - 1;
     struct K {
         PmK m;
-        const FHE_GLOBAL PmRaw *tw, *twi;
+        const FHE_CONST PmRaw *tw, *twi;
         PmTw ninv;    // n^-1 (or 1) in twiddle form
         PmTw ninv_w;  // n^-1 * twi[1] (whole rings only, pb = 0)
         int pb, prefix;
@@ -196,7 +207,7 @@ struct ArithPM {
     static __host__ __device__ __forceinline__ u64 pack(u64 w) { return ((w >> (B - 31)) << 32) | (w & ((u64(1) << (B - 31)) - 1)); }
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
-        const FHE_GLOBAL PmRaw *p = (INV ? k.twi : k.tw) + idx;
+        const FHE_CONST PmRaw *p = (INV ? k.twi : k.tw) + idx;
         TwRaw r;
         r.x = p->x; r.y = p->y;
         return r;
@@ -213,7 +224,7 @@ struct ArithPM {
         K k;
         k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
         k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c;
-        k.tw = (const FHE_GLOBAL PmRaw *)D.tww; k.twi = (const FHE_GLOBAL PmRaw *)D.twwi;
+        k.tw = (const FHE_CONST PmRaw *)D.tww; k.twi = (const FHE_CONST PmRaw *)D.twwi;
         k.ninv = split(pb ? 1 : D.ninv[log_n_total]);
         k.ninv_w = split(D.ninv_w[log_n_total]);
         k.pb = pb; k.prefix = prefix;
@@ -240,12 +251,15 @@ struct ArithPM {
         Y = pm_mul<B>(d, w, k.m);
     }
     static constexpr bool GS_FOLDS = true;
+    static constexpr int GS_SPAN = 0;  // pairs of layers inside a network
     // last inverse layer, n^-1 folded in (see ArithShoup::gs_last_scaled); PH = 1 inputs (sums < 2q +, products < q +)
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
         const u64 s = X + Y, d = X - Y + k.m.q4;
         X = csub(pm_mul<B>(s, k.ninv, k.m), k.m.q);
         Y = csub(pm_mul<B>(d, k.ninv_w, k.m), k.m.q);
     }
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const PmTw &w, const K &k) {
         const u64 s = X + Y, d = X - Y + k.m.q4;
         X = csub(fold1(s, k.m), k.m.q);
@@ -306,7 +320,7 @@ struct ArithDS {
     typedef uint4 TwReg;
     struct K {
         DsK m;
-        const FHE_GLOBAL uint4 *tw, *twi;
+        const FHE_CONST uint4 *tw, *twi;
         uint4 ninv, ninv_w;
         int pb, prefix;
     };
@@ -318,7 +332,7 @@ struct ArithDS {
     }
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
-        const FHE_GLOBAL uint4 *p = (INV ? k.twi : k.tw) + idx;
+        const FHE_CONST uint4 *p = (INV ? k.twi : k.tw) + idx;
         TwRaw r;
         r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
         return r;
@@ -328,7 +342,7 @@ struct ArithDS {
         K k;
         k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
         k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c; k.m.pw = D.ds_pow;
-        k.tw = as_global(D.twd); k.twi = as_global(D.twdi);
+        k.tw = as_const(D.twd); k.twi = as_const(D.twdi);
         k.ninv = split(pb ? 1 : D.ninv[log_n_total], D.q);
         k.ninv_w = split(D.ninv_w[log_n_total], D.q);
         k.pb = pb; k.prefix = prefix;
@@ -357,21 +371,28 @@ struct ArithDS {
     static constexpr bool PASS_FOLD = false;                  // ... nor to pass boundaries:
     static constexpr int CT_SPAN = B >= 64 - 2 ? 1 : (((1 << (64 - B)) - 2) / 2 > 64 ? 64 : ((1 << (64 - B)) - 2) / 2);
     static __device__ constexpr bool ct_fold_at(int layer) { return layer > 0 && layer % CT_SPAN == 0; }  // before this layer of the transform
+    // Inverse butterfly, PH = layers since the sums were last folded: inputs < 2^PH (q + eps), so the difference takes the offset
+    // 2^(PH+1) q and the sum stays below 2^(PH+1) (q + eps): 64 - B - 1 layers between two folds (3 at 60 bits: 12 q + 8 q < 2^64).
     template <int PH>
     static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &w, const K &k) {
+        static_assert(PH < 64 - B - 1, "sums overflow");
         const u64 s = X + Y;
-        const u64 d = X + (PH ? k.m.q4 : k.m.q2) - Y;
+        const u64 d = X + (k.m.q2 << PH) - Y;
         X = s;
         Y = mul(d, w, k.m);
     }
     static constexpr bool GS_FOLDS = true;
+    static constexpr int GS_SPAN = 64 - B - 1 > 8 ? 8 : 64 - B - 1;  // kernels that pass their global step fold every GS_SPAN-th layer
+    // last inverse layer (PH as in gs): a whole ring folds n^-1 into it, see ArithShoup::gs_last_scaled
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &k) {
-        const u64 s = X + Y, d = X + k.m.q4 - Y;
+        const u64 s = X + Y, d = X + (k.m.q2 << PH) - Y;
         X = csub(mul(s, k.ninv, k.m), k.m.q);
         Y = csub(mul(d, k.ninv_w, k.m), k.m.q);
     }
+    template <int PH = 1>
     static __device__ __forceinline__ void gs_last_plain(u64 &X, u64 &Y, const TwReg &w, const K &k) {
-        const u64 s = X + Y, d = X + k.m.q4 - Y;
+        const u64 s = X + Y, d = X + (k.m.q2 << PH) - Y;
         X = csub(fold1(s, k.m), k.m.q);
         Y = csub(mul(d, w, k.m), k.m.q);
     }
@@ -451,11 +472,14 @@ __device__ __forceinline__ void ct_apply(typename A::Elem (&x)[E], const typenam
 }
 
 // inverse: the unit of layer l is step R-1-l of its network; PH = step & 1 pairs layers for the lazy policies, sums are
-// folded after every second layer and after the last layer of a network with an odd layer count
-template <class A, class U, int NTW, int E>
+// folded after every second layer and after the last layer of a network with an odd layer count.  GSTEP >= 0 (kernels that know
+// where a unit sits in the WHOLE transform, ntt14w.hpp): policies with a GS_SPAN fold every GS_SPAN-th layer of the transform
+// instead (PH = layers since the last fold), whatever the pass boundaries are.
+template <class A, class U, int GSTEP = -1, int NTW, int E>
 __device__ __forceinline__ void gs_apply(typename A::Elem (&x)[E], const typename A::TwRaw (&raw)[NTW], const typename A::K &k) {
-    constexpr int step = U::R - 1 - U::l, PH = step & 1;
-    constexpr bool FOLD = A::GS_FOLDS && (PH == 1 || step == U::R - 1);
+    constexpr bool GLOBAL = GSTEP >= 0 && A::GS_SPAN > 0;
+    constexpr int step = U::R - 1 - U::l, PH = GLOBAL ? GSTEP % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : (step & 1);
+    constexpr bool FOLD = A::GS_FOLDS && (GLOBAL ? PH == A::GS_SPAN - 1 : (PH == 1 || step == U::R - 1));
     static_for<0, (U::SHARED ? (1 << U::l) : U::NREP)>([&](auto oc) {
         constexpr int outer = decltype(oc)::value;
         static_for<0, (U::SHARED ? U::NREP : (1 << U::l))>([&](auto ic) {

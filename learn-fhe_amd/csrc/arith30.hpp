@@ -29,6 +29,7 @@ struct Arith30 {
     static constexpr bool GS_FOLDS = false;
     static constexpr int CT_LAYERS = 64;  // Harvey butterflies renormalise every layer
     static constexpr bool PASS_FOLD = false;
+    static constexpr int GS_SPAN = 0;
     static __device__ constexpr bool ct_fold_at(int) { return false; }
     struct K {
         unsigned p, p2;

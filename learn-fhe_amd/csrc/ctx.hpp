@@ -23,6 +23,7 @@ struct fhe_ctx {
     int device = -1;
     fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM
     u64 *d_tww = nullptr, *d_twwi = nullptr;        // plain twiddles for the pseudo-Mersenne path (null if not eligible)
+    uint4 *d_twd = nullptr, *d_twdi = nullptr;      // the same twiddles in the two-operand split form (ArithDS, arith.hpp)
     int pm_b = 0;                                   // q = 2^pm_b - pm_c, or 0
     unsigned pm_c = 0;
     fhe::ModDesc *d_desc = nullptr;                 // this modulus as the kernels read it (1 entry)

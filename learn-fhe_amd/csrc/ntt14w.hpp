@@ -1,0 +1,488 @@
+// N = 2^14 transform kernels, wave-local form (BASELINE config 2, and the sub-transforms of 2^15..2^17 rings).
+//
+// A polynomial lives in the registers of a 512-thread workgroup (32 coefficients per thread, two workgroups per CU) as in
+// the first register-resident kernel, but the index bits are dealt so that after the first three layers every WAVE owns one
+// independent sub-transform of 2^11 coefficients (the classic four-step split: layers 0..2 couple the eight blocks of 2^11,
+// layers 3..13 stay inside a block).  Only ONE exchange crosses waves (workgroup barriers); the other two are wave-private
+// (the wave's own LDS region, ordered by its own lgkmcnt), so the eight waves of a workgroup drift apart and one wave's
+// exchange latency hides behind another wave's butterflies.  4 barriers per transform instead of 12.
+//
+//   wave w0 = i[8:6] , lane = i[5:0]                                            (i = coefficient index, 14 bits)
+//   pass 0: regs {13,12,11 | 10,9}   layers 0..2    HBM side: 8-byte coalesced accesses; twiddles wave-uniform (SGPRs)
+//   ---- X01: across waves, two rounds split by bit 10, lanes keep i[5:0] ------------------------------------------------
+//   wave w = i[13:11] from here on
+//   pass 1: regs {10,9,8,7 | 6}      lane = i[5:0]                  layers 3..6     twiddles wave-uniform (SGPRs)
+//   ---- X12: wave-private, split by bit 6 -----------------------------------------------------------------------------
+//   pass 2: regs {6,5,4,3 | 2}       lane = (i[10:7], i[1:0])       layers 7..10    15 twiddles per thread
+//   ---- X23: wave-private, split by bit 2 -----------------------------------------------------------------------------
+//   pass 3: regs {2,1,0 | 10,9}      lane = i[8:3]                  layers 11..13   28 twiddles per thread
+//                                                                   HBM side: 64 contiguous bytes per lane and (10,9) value
+//
+// The passive register bits (after the bar) sit BELOW the bits a pass processes in passes 0..2, so its replicas share their
+// twiddles.  Forward = passes 0 -> 3 (Cooley-Tukey, util/src/ring/fft.rs:40-54), inverse = 3 -> 0 (Gentleman-Sande, 59-77, n^-1
+// folded into the last layer).  Natural-order coefficients <-> bit-reversed evaluations, twiddle tw[2^layer + block], exactly
+// as the reference.  LDS layouts are conflict free for ds_write_b64 / ds_read_b64 (tools/lds_bank_sim.py).
+#pragma once
+#include "ntt_kernels.hpp"
+
+namespace fhe {
+namespace w14 {
+
+constexpr int THREADS = 512;
+constexpr int WSLOTS = 1088;                         // wave-private region: 1024 coefficients + padding, in u64 slots
+constexpr size_t LDS_BYTES = size_t(8) * WSLOTS * 8;  // 69 632 B -> two workgroups per CU; X01 uses the first 64 KiB of it
+
+// A wave's LDS instructions execute in issue order: inside a wave-private exchange a read issued after a write sees it, and a
+// write issued after a read cannot overtake it.  All that is needed is that the COMPILER keeps the order (a workgroup-scope
+// fence would also drain vmcnt, i.e. make every exchange wait for the twiddle fetches that are deliberately left in flight
+// across it).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+// An exchange is a short burst of LDS instructions: latency critical, while the other waves of the SIMD are usually inside a
+// butterfly pass (throughput bound).  W14_XCHG_PRIO: exchanging waves take issue priority (lab switch; see DESIGN.md for the A/B).
+#ifndef W14_XCHG_PRIO
+#define W14_XCHG_PRIO 0
+#endif
+#if W14_XCHG_PRIO
+#define W14_PRIO_UP() __builtin_amdgcn_s_setprio(3)
+#define W14_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define W14_PRIO_UP()
+#define W14_PRIO_DOWN()
+#endif
+
+#ifdef NTT14_STAMPS
+__device__ unsigned long long g_stamps[4096][16];
+#define STAMP_DECL unsigned long long stamps_[12]
+#define STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps_[i])::"memory")
+#define STAMP_REAL(i) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps_[i])::"memory")  /* 100 MHz */
+#define STAMP_FLUSH()                                                                       \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                          \
+            for (int i_ = 0; i_ < 12; ++i_) g_stamps[blockIdx.x][i_] = stamps_[i_];        \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_REAL(i)
+#define STAMP_FLUSH()
+#endif
+
+// ---- register naming -----------------------------------------------------------------------------------------------
+//   pass 0: x[(s2 << 3) | n3]    n3 = i[13:11], s2 = i[10:9]
+//   pass 1: x[(s << 4) | n4]     n4 = i[10:7],  s = i[6]
+//   pass 2: x[(s << 4) | n4]     n4 = i[6:3],   s = i[2]
+//   pass 3: x[(ab << 3) | n3]    n3 = i[2:0],   ab = i[10:9]
+
+// pass 0 -> pass 1 (across waves; round h moves the coefficients with i[10] = h)
+__device__ __forceinline__ void xchg_01(u64 (&x)[32], int t, int w, u64 *lds) {
+    u64 *wp = lds + t, *rp = lds + (w << 10) + (t & 63);  // constant offsets from here on: immediates of the ds instructions
+    u64 y[32];
+    W14_PRIO_UP();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int b9 = 0; b9 < 2; ++b9)
+#pragma unroll
+            for (int n3 = 0; n3 < 8; ++n3) wp[(n3 << 10) | (b9 << 9)] = x[((((h << 1) | b9)) << 3) | n3];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {  // m = (i9 i8 i7 i6)
+            const int n4 = (h << 3) | (m >> 1), s = m & 1;
+            y[(s << 4) | n4] = rp[m << 6];
+        }
+        __syncthreads();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+__device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, int w, u64 *lds) {
+    u64 *rp = lds + t, *wp = lds + (w << 10) + (t & 63);
+    u64 y[32];
+    W14_PRIO_UP();
+    __syncthreads();  // every wave has left its private region
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int n4 = (h << 3) | (m >> 1), s = m & 1;
+            wp[m << 6] = x[(s << 4) | n4];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b9 = 0; b9 < 2; ++b9)
+#pragma unroll
+            for (int n3 = 0; n3 < 8; ++n3) y[((((h << 1) | b9)) << 3) | n3] = rp[(n3 << 10) | (b9 << 9)];
+        if (h == 0) __syncthreads();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+// pass 1 -> pass 2 (wave-private; round h moves i[6] = h).  Slot of (i[10:7] = n4, i[5:0] = l6): 68 n4 + l6.
+__device__ __forceinline__ void xchg_12(u64 (&x)[32], int lane, u64 *wl) {
+    u64 *wp = wl + lane;
+    const u64 *rp = wl + 68 * (lane >> 2) + (lane & 3);  // as pass-2 lane (i[10:7], i[1:0]); + 4 (i[5:2])
+    u64 y[32];
+    W14_PRIO_UP();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int n4 = 0; n4 < 16; ++n4) wp[68 * n4] = x[(h << 4) | n4];
+        wave_sync();
+#pragma unroll
+        for (int r4 = 0; r4 < 16; ++r4)  // r4 = i[5:2] -> pass-2 register n4 = (h, i5, i4, i3), s = i2
+            y[((r4 & 1) << 4) | (h << 3) | (r4 >> 1)] = rp[4 * r4];
+        wave_sync();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+__device__ __forceinline__ void xchg_21(u64 (&x)[32], int lane, u64 *wl) {
+    u64 *wp = wl + 68 * (lane >> 2) + (lane & 3);
+    const u64 *rp = wl + lane;
+    u64 y[32];
+    W14_PRIO_UP();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r4 = 0; r4 < 16; ++r4) wp[4 * r4] = x[((r4 & 1) << 4) | (h << 3) | (r4 >> 1)];
+        wave_sync();
+#pragma unroll
+        for (int n4 = 0; n4 < 16; ++n4) y[(h << 4) | n4] = rp[68 * n4];
+        wave_sync();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+// pass 2 -> pass 3 (wave-private; round h moves i[2] = h).  Slot of a coefficient: with hi5 = (i10 i9 i1 i0 i8),
+// 34 hi5 + 2 i[6:3] + i7  (= (hi5 << 5 | i[6:3] << 1 | i7) + 2 hi5: two pad slots per 32).
+__device__ __forceinline__ void xchg_23(u64 (&x)[32], int lane, u64 *wl) {
+    // as pass-2 lane (i10 i9 i8 i7 i1 i0)
+    const int hi5 = ((lane >> 4) << 3) | ((lane & 3) << 1) | ((lane >> 3) & 1);
+    u64 *wp = wl + 34 * hi5 + ((lane >> 2) & 1);  // + 2 i[6:3]
+    // as pass-3 lane i[8:3]: 34 i8 + 2 i[6:3] + i7;  + 68 (i10 i9 i1 i0)
+    const u64 *rp = wl + 34 * (lane >> 5) + 2 * (lane & 15) + ((lane >> 4) & 1);
+    u64 y[32];
+    W14_PRIO_UP();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wp[2 * c] = x[(h << 4) | c];
+        wave_sync();
+#pragma unroll
+        for (int R = 0; R < 16; ++R)  // R = (i10 i9 i1 i0) -> pass-3 register ab = R >> 2, n3 = (h, i1, i0)
+            y[((R >> 2) << 3) | (h << 2) | (R & 3)] = rp[68 * R];
+        wave_sync();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+// pass 3 -> pass 2 (inverse direction).  Its own layout (each direction picks the one that is conflict free for ITS writes and
+// reads): slot = 17 L + i[6:3] with L = the pass-2 lane number (i10 i9 i8 i7 i1 i0).
+__device__ __forceinline__ void xchg_32(u64 (&x)[32], int lane, u64 *wl) {
+    const u64 *rp = wl + 17 * lane;                        // as pass-2 lane; + i[6:3]
+    u64 *wp = wl + 68 * (lane >> 4) + (lane & 15);         // as pass-3 lane i[8:3]: 17 ((i8 i7) << 2) + i[6:3]; + 17 ((i10 i9) << 4 | (i1 i0))
+    u64 y[32];
+    W14_PRIO_UP();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int R = 0; R < 16; ++R) wp[17 * (((R >> 2) << 4) | (R & 3))] = x[((R >> 2) << 3) | (h << 2) | (R & 3)];
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) y[(h << 4) | c] = rp[c];
+        wave_sync();
+    }
+    W14_PRIO_DOWN();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = y[r];
+}
+
+// units (arith.hpp): passes 0..2 are replicas sharing twiddles; pass 3 is one replica (i[10:9] = AB) at a time with its own
+template <int l> using P0 = Unit<0, 3, l, 0, 4, 8, true>;
+template <int l> using P1 = Unit<3, 4, l, 0, 2, 16, true>;
+template <int l> using P2 = Unit<7, 4, l, 0, 2, 16, true>;
+template <int l, int AB> using P3 = Unit<11, 3, l, AB, 1, 8, false, 6>;  // block prefix (w << 8) | (AB << 6) | lane
+
+// one replica's pass-3 twiddles (layers 11, 12, 13)
+template <class A>
+struct Tw7 {
+    typename A::TwRaw l0[1], l1[2], l2[4];
+};
+template <class A, bool INV, int AB>
+__device__ __forceinline__ void tw7_load(Tw7<A> &b, int t3, const typename A::K &k) {
+    tw_load<A, INV, P3<0, AB>>(b.l0, t3, k);
+    tw_load<A, INV, P3<1, AB>>(b.l1, t3, k);
+    tw_load<A, INV, P3<2, AB>>(b.l2, t3, k);
+}
+
+// HBM side of pass 0: register (s2, n3) <-> coefficient (n3 << 11) | (s2 << 9) | t, consecutive lanes on consecutive words
+template <int S2>
+__device__ __forceinline__ void load_p0(u64 (&x)[32], const u64 *__restrict__ g, int t) {
+#ifdef W14_ABLATE_NO_GLOBAL  // developer lab only: no HBM traffic
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) x[S2 * 8 + n3] = (u64)(t + n3 + S2) * 0x9E3779B97F4A7C15ull >> 5;
+#else
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) x[S2 * 8 + n3] = g[(n3 << 11) | (S2 << 9) | t];
+#endif
+}
+// HBM side of pass 3 (inverse loads): register (ab, n3) <-> coefficient (w << 11) | (ab << 9) | (lane << 3) | n3
+template <int AB>
+__device__ __forceinline__ void load_p3(u64 (&x)[32], const u64 *__restrict__ src) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + (AB << 9) + j);
+        x[AB * 8 + j] = v.x; x[AB * 8 + j + 1] = v.y;
+    }
+}
+
+// Forward stores.  A pass-3 lane owns 64 contiguous bytes per (i10 i9) value; stored as they stand, every 16-byte store
+// instruction would touch 32 lines (measured: the store side alone then runs at 4.4 TB/s instead of 5.0).  The finished
+// replica goes through the wave's LDS region once more (slot e + 2 (e >> 4): ds_write_b128 conflict free, ds_read_b128 two-way)
+// and leaves as four 1 KiB-contiguous store instructions.
+template <class A, int AB>
+__device__ __forceinline__ void store_p3(u64 (&x)[32], u64 *__restrict__ dst_wave, int lane, u64 *wl, const typename A::K &k) {
+    ulonglong2 *wr = reinterpret_cast<ulonglong2 *>(wl + 8 * lane + (lane & ~1));
+    const ulonglong2 *rd = reinterpret_cast<const ulonglong2 *>(wl + 2 * lane + 2 * (lane >> 3));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ulonglong2 v;
+        v.x = A::canon_fwd(x[AB * 8 + 2 * j], k);
+        v.y = A::canon_fwd(x[AB * 8 + 2 * j + 1], k);
+        wr[j] = v;
+    }
+    wave_sync();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {  // back into the replica's own registers (a local array here is kept in scratch memory)
+        const ulonglong2 v = rd[72 * kk];  // 144 slots
+        x[AB * 8 + 2 * kk] = v.x; x[AB * 8 + 2 * kk + 1] = v.y;
+    }
+    wave_sync();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        ulonglong2 v;
+        v.x = x[AB * 8 + 2 * kk]; v.y = x[AB * 8 + 2 * kk + 1];
+#ifdef W14_ABLATE_NO_GLOBAL
+        if (v.x == 0xdeadbeefcafef00dull)
+#endif
+        *reinterpret_cast<ulonglong2 *>(dst_wave + (AB << 9) + 128 * kk + 2 * lane) = v;
+    }
+}
+
+// One forward transform.  x[] arrives loaded (pass-0 layout, the loads possibly still in flight).
+template <class A>
+__device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
+                                        const int t, const int lane, const int w) {
+    typedef typename A::TwRaw Tw;
+    STAMP_DECL;
+    STAMP_REAL(10);
+    STAMP(0);
+    {   // pass 0: layers 0..2, twiddles wave-uniform
+        Tw a0[1], a1[2], a2[4];
+        tw_load<A, false, P0<0>>(a0, 0, k); tw_load<A, false, P0<1>>(a1, 0, k); tw_load<A, false, P0<2>>(a2, 0, k);
+        STAMP(1);
+        FHE_SCHED_FENCE();
+        ct_apply<A, P0<0>>(x, a0, k);
+        FHE_SCHED_FENCE();
+        ct_apply<A, P0<1>>(x, a1, k);
+        FHE_SCHED_FENCE();
+        ct_apply<A, P0<2>>(x, a2, k);
+    }
+    FHE_SCHED_FENCE();
+    Tw b0[1], b1[2], b2[4], b3[8];  // pass 1: wave-uniform as well (block prefix = w): fetched behind the barriers of X01
+    tw_load<A, false, P1<0>>(b0, w, k); tw_load<A, false, P1<1>>(b1, w, k); tw_load<A, false, P1<2>>(b2, w, k); tw_load<A, false, P1<3>>(b3, w, k);
+    STAMP(2);
+    xchg_01(x, t, w, lds);
+    STAMP(3);
+    if constexpr (A::PASS_FOLD) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
+    FHE_SCHED_FENCE();
+    ct_apply<A, P1<0>>(x, b0, k);
+    FHE_SCHED_FENCE();
+    ct_apply<A, P1<1>>(x, b1, k);
+    FHE_SCHED_FENCE();
+    ct_apply<A, P1<2>>(x, b2, k);
+    FHE_SCHED_FENCE();
+    ct_apply<A, P1<3>>(x, b3, k);
+    FHE_SCHED_FENCE();
+    const int t2 = (w << 4) | (lane >> 2), t3 = (w << 8) | lane;
+    Tw c0[1], c1[2], c2[4], c3[8];  // pass 2: per lane; the first seven ride through X12
+    tw_load<A, false, P2<0>>(c0, t2, k); tw_load<A, false, P2<1>>(c1, t2, k); tw_load<A, false, P2<2>>(c2, t2, k);
+    STAMP(4);
+    xchg_12(x, lane, wl);
+    STAMP(5);
+    if constexpr (A::PASS_FOLD) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
+    FHE_SCHED_FENCE();
+    ct_apply<A, P2<0>>(x, c0, k);
+    FHE_SCHED_FENCE();
+    ct_apply<A, P2<1>>(x, c1, k);
+    FHE_SCHED_FENCE();
+    tw_load<A, false, P2<3>>(c3, t2, k);
+    ct_apply<A, P2<2>>(x, c2, k);
+    FHE_SCHED_FENCE();
+    ct_apply<A, P2<3>>(x, c3, k);
+    FHE_SCHED_FENCE();
+    Tw7<A> d[2];  // pass 3: one replica ahead
+    tw7_load<A, false, 0>(d[0], t3, k);
+    STAMP(6);
+    xchg_23(x, lane, wl);
+    STAMP(7);
+    if constexpr (A::PASS_FOLD) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
+    }
+    u64 *dst_wave = g + (w << 11);
+    static_for<0, 4>([&](auto abc) {
+        constexpr int ab = decltype(abc)::value;
+        FHE_SCHED_FENCE();
+        ct_apply<A, P3<0, ab>>(x, d[ab & 1].l0, k);
+        ct_apply<A, P3<1, ab>>(x, d[ab & 1].l1, k);
+        FHE_SCHED_FENCE();
+        if constexpr (ab < 3) tw7_load<A, false, (ab < 3 ? ab + 1 : 3)>(d[(ab + 1) & 1], t3, k);
+        ct_apply<A, P3<2, ab>>(x, d[ab & 1].l2, k);
+        FHE_SCHED_FENCE();
+        store_p3<A, ab>(x, dst_wave, lane, wl, k);
+    });
+    STAMP(8);
+#ifdef NTT14_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic builds only: when have the stores left?
+#endif
+    STAMP(9);
+    STAMP_REAL(11);
+    STAMP_FLUSH();
+}
+
+// One inverse transform; x[] arrives loaded in the pass-3 layout, d[] with the pass-3 twiddles of replicas 0 and 1 (fetched BEFORE
+// the coefficients: vmcnt retires in order, and the twiddles are L2 hits).
+template <class A, bool PFX>
+__device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
+                                        const int t, const int lane, const int w) {
+    typedef typename A::TwRaw Tw;
+    const int t2 = (w << 4) | (lane >> 2), t3 = (w << 8) | lane;
+    static_for<0, 4>([&](auto abc) {  // pass 3: layers 13, 12, 11; twiddles two replicas ahead (d[] arrives holding replicas 0 and 1)
+        constexpr int ab = decltype(abc)::value;
+        FHE_SCHED_FENCE();
+        gs_apply<A, P3<2, ab>, 0>(x, d[ab & 1].l2, k);
+        FHE_SCHED_FENCE();
+        gs_apply<A, P3<1, ab>, 1>(x, d[ab & 1].l1, k);
+        gs_apply<A, P3<0, ab>, 2>(x, d[ab & 1].l0, k);
+        FHE_SCHED_FENCE();
+        if constexpr (ab < 2) tw7_load<A, true, (ab < 2 ? ab + 2 : 3)>(d[ab & 1], t3, k);
+    });
+    FHE_SCHED_FENCE();
+    Tw c3[8], c2[4], c1[2], c0[1];
+    tw_load<A, true, P2<3>>(c3, t2, k);
+    xchg_32(x, lane, wl);
+    FHE_SCHED_FENCE();
+    tw_load<A, true, P2<2>>(c2, t2, k);
+    gs_apply<A, P2<3>, 3>(x, c3, k);
+    FHE_SCHED_FENCE();
+    tw_load<A, true, P2<1>>(c1, t2, k); tw_load<A, true, P2<0>>(c0, t2, k);
+    gs_apply<A, P2<2>, 4>(x, c2, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P2<1>, 5>(x, c1, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P2<0>, 6>(x, c0, k);
+    FHE_SCHED_FENCE();
+    Tw b3[8], b2[4], b1[2], b0[1];  // wave-uniform
+    tw_load<A, true, P1<3>>(b3, w, k); tw_load<A, true, P1<2>>(b2, w, k); tw_load<A, true, P1<1>>(b1, w, k); tw_load<A, true, P1<0>>(b0, w, k);
+    xchg_21(x, lane, wl);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P1<3>, 7>(x, b3, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P1<2>, 8>(x, b2, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P1<1>, 9>(x, b1, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P1<0>, 10>(x, b0, k);
+    FHE_SCHED_FENCE();
+    Tw a2[4], a1[2], a0[1];
+    tw_load<A, true, P0<2>>(a2, 0, k); tw_load<A, true, P0<1>>(a1, 0, k);
+    if constexpr (PFX) tw_load<A, true, P0<0>>(a0, 0, k);
+    xchg_10(x, t, w, lds);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P0<2>, 11>(x, a2, k);
+    FHE_SCHED_FENCE();
+    gs_apply<A, P0<1>, 12>(x, a1, k);
+    // the last layer leaves canonical values: a whole ring folds n^-1 into it (the difference branch multiplies by twi[1] n^-1),
+    // a sub-transform of a larger ring is not scaled here at all
+    typename A::TwReg wlast{};
+    if constexpr (PFX) wlast = A::prep(a0[0]);
+    constexpr int LAST_PH = A::GS_SPAN > 0 ? 13 % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : 1;  // layers since the sums were last folded
+    static_for<0, 4>([&](auto sc) {
+        constexpr int s2 = decltype(sc)::value;
+        FHE_SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = s2 * 8 + j;
+            if constexpr (PFX) A::template gs_last_plain<LAST_PH>(x[o], x[o + 4], wlast, k);
+            else A::template gs_last_scaled<LAST_PH>(x[o], x[o + 4], k);
+            g[(j << 11) | (s2 << 9) | t] = x[o];
+            g[((j + 4) << 11) | (s2 << 9) | t] = x[o + 4];
+        }
+    });
+}
+
+}  // namespace w14
+
+// One workgroup = one (sub-)polynomial.  (A persistent variant -- two workgroups per CU looping over polynomials, the next one's
+// HBM loads issued behind the last twiddle fetch of the current one -- measured 8-10 % SLOWER at 4096 polynomials than letting
+// the hardware dispatch one-polynomial workgroups: 0.319-0.324 ms against 0.293 ms, tools/ntt_lab2.hip.)
+// PFX = false: whole 2^14 rings (pb = 0).  PFX = true: sub s is sub-transform s & (2^pb - 1) of polynomial s >> pb.
+template <class A, bool PFX>
+__global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
+                                                                       unsigned subs, int pb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned sub = blockIdx.x;
+    const unsigned poly = PFX ? sub >> pb : sub;
+    const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
+    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    u64 *g = data + (size_t(sub) << 14);
+    u64 x[32];
+    w14::load_p0<0>(x, g, t); w14::load_p0<1>(x, g, t); w14::load_p0<2>(x, g, t); w14::load_p0<3>(x, g, t);
+    w14::fwd_one<A>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+}
+
+template <class A, bool PFX>
+__global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
+                                                                       unsigned subs, int pb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned sub = blockIdx.x;
+    const unsigned poly = PFX ? sub >> pb : sub;
+    const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
+    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    u64 *g = data + (size_t(sub) << 14);
+    u64 x[32];
+    w14::Tw7<A> d[2];
+    w14::tw7_load<A, true, 0>(d[0], (w << 8) | lane, k);
+    w14::tw7_load<A, true, 1>(d[1], (w << 8) | lane, k);
+    const u64 *src = g + ((w << 11) | (lane << 3));
+    w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
+    w14::inv_one<A, PFX>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+}
+
+}  // namespace fhe

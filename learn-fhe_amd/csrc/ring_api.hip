@@ -2,13 +2,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
+#include <utility>
 
 #include "../../include/fhe_ring.h"
 #include "api_common.hpp"
 #include "ctx.hpp"
 #include "ntt_kernels.hpp"
-#include "ntt14.hpp"
+#include "ntt14w.hpp"
 
 using fhe::u64;
 
@@ -23,6 +26,20 @@ int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
     return FHE_OK;
 }
 
+// hipFuncSetAttribute once per (kernel, device), not per launch
+hipError_t set_max_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
+}
+
 template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false>
 int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
@@ -30,7 +47,7 @@ int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a,
     // for the inverse
     auto k = inverse ? fhe::ntt_inv_kernel<A, LOG_N, LOG_E, PPW, PFX, true> : fhe::ntt_fwd_kernel<A, LOG_N, LOG_E, PPW, PFX, false>;
     if (C::LDS_BYTES > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        HIP_TRY(set_max_lds((const void *)k, (int)C::LDS_BYTES));
     unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());
@@ -65,15 +82,17 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
     }
 }
 
-// N = 2^14 (and the 2^14 sub-transforms of larger rings): the register-resident kernels of ntt14.hpp, two workgroups per
-// CU; measured faster than the LDS-resident generic kernel in both directions and for both arithmetic policies
-// (tools/ntt_lab.hip: 0.446 / 0.448 ms against 0.486 / 0.481 ms for 4096 pseudo-Mersenne transforms)
-template <class A>
+// N = 2^14 (and the 2^14 sub-transforms of larger rings): the register-resident, wave-local kernels of ntt14w.hpp, two
+// workgroups per CU.  AF / AI: the arithmetic policy of each direction (measured, tools/ntt_lab2.hip, 4096 transforms at 60 bits:
+// forward 0.280 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.345 against
+// 0.320 -- the inverse's per-lane twiddles are needed first, while the coefficients are still on their way from HBM, and the
+// 16-byte form makes that wait longer than the instructions it saves).
+template <class AF, class AI>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
-    auto k = pb ? (inv ? fhe::ntt14_inv_kernel<A, true> : fhe::ntt14_fwd_kernel<A, true>)
-                : (inv ? fhe::ntt14_inv_kernel<A, false> : fhe::ntt14_fwd_kernel<A, false>);
-    HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fhe::N14_LDS_BYTES));
-    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::N14_THREADS), fhe::N14_LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
+    auto k = pb ? (inv ? fhe::ntt14w_inv_kernel<AI, true> : fhe::ntt14w_fwd_kernel<AF, true>)
+                : (inv ? fhe::ntt14w_inv_kernel<AI, false> : fhe::ntt14w_fwd_kernel<AF, false>);
+    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::THREADS), fhe::w14::LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
@@ -82,11 +101,11 @@ int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, 
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
     if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st);
-    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st)
+    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st)
                                      : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st);
-    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st)
+    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st)
                                      : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st);
-    return log_n == 14 ? launch14<fhe::ArithShoup>(inv, d, nd, a, subs, pb, st)
+    return log_n == 14 ? launch14<fhe::ArithShoup, fhe::ArithShoup>(inv, d, nd, a, subs, pb, st)
                        : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st);
 }
 int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
@@ -173,7 +192,7 @@ int ctx_build_host(uint64_t q, fhe_ctx *c) {
         c->ninv_w_s[k] = shoup(c->ninv_w[k], q);
     }
     int nbits = 64 - __builtin_clzll(q);
-    // pseudo-Mersenne eligibility (ntt14.hpp): q = 2^b - c with 33 <= b <= 60 and c <= 2^(b-33)
+    // pseudo-Mersenne eligibility (arith.hpp): q = 2^b - c with 33 <= b <= 60 and c <= 2^(b-33)
     c->pm_b = 0; c->pm_c = 0;
     if (nbits >= 34 && nbits <= 60) {
         const uint64_t cc = (uint64_t(1) << nbits) - q;
@@ -235,8 +254,25 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
             if (e == hipSuccess) e = hipMemcpy(c->d_tww, lf.data(), cap * sizeof(uint64_t), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(c->d_twwi, li.data(), cap * sizeof(uint64_t), hipMemcpyHostToDevice);
         }
+        if (e == hipSuccess && c->pm_b) {
+            // ... and in the 16-byte two-operand form {a0, a1, b0, b1} of ArithDS (w and w 2^32 mod q, each split at b - 31 bits)
+            const int b = c->pm_b;
+            std::vector<uint4> df(cap), di(cap);
+            auto split = [b, q](uint64_t w) {
+                const uint64_t w1 = (uint64_t)((((unsigned __int128)w) << 32) % q), lo = (uint64_t(1) << (b - 31)) - 1;
+                return uint4{(unsigned)(w & lo), (unsigned)(w >> (b - 31)), (unsigned)(w1 & lo), (unsigned)(w1 >> (b - 31))};
+            };
+            for (size_t j = 0; j < cap; ++j) { df[j] = split(c->tw[j]); di[j] = split(c->twi[j]); }
+            e = hipMalloc((void **)&c->d_twd, 2 * cap * sizeof(uint4));
+            c->d_twdi = c->d_twd + cap;
+            if (e == hipSuccess) e = hipMemcpy(c->d_twd, df.data(), cap * sizeof(uint4), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->d_twdi, di.data(), cap * sizeof(uint4), hipMemcpyHostToDevice);
+        }
         c->h_desc.tww = c->d_tww;
         c->h_desc.twwi = c->d_twwi;
+        c->h_desc.twd = c->d_twd;
+        c->h_desc.twdi = c->d_twdi;
+        c->h_desc.ds_pow = c->pm_b ? 1u << (c->pm_b - 31) : 0;
         c->h_desc.pm_b = c->pm_b;
         c->h_desc.pm_c = c->pm_c;
         c->h_desc.q = q;
@@ -267,6 +303,7 @@ void fhe_ctx_destroy(fhe_ctx *c) {
         if (c->d_twi) (void)hipFree(c->d_twi);
         if (c->d_desc) (void)hipFree(c->d_desc);
         if (c->d_tww) (void)hipFree(c->d_tww);
+        if (c->d_twd) (void)hipFree(c->d_twd);
     }
     delete c;
 }

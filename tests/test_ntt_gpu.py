@@ -65,7 +65,7 @@ def test_golden_vectors(fhe, torch_cuda):
 def test_forward_inverse_vs_oracle(fhe, cref, torch_cuda, log_n):
     """every supported size, three moduli widths, ragged batch (not a multiple of the polynomials per workgroup)"""
     n = 1 << log_n
-    # 60-/54-bit primes of two_adic_primes are pseudo-Mersenne eligible (ntt14.hpp ArithPM), 45-/61-bit ones are not (Shoup)
+    # 60-/54-bit primes of two_adic_primes are pseudo-Mersenne eligible (ntt14w.hpp: ArithDS forward, ArithPM inverse), 45-/61-bit ones are not (Shoup)
     cases = [(45, 3), (30, 2), (60, 2)] if log_n <= 12 else [(60, 2), (54, 1), (45, 1), (61, 1)]
     for bits, count in cases:
         if bits <= log_n + 1:

@@ -1,4 +1,4 @@
-// Developer lab 2: A/B of arithmetic policies inside the N = 2^14 kernels (ntt14.hpp), interleaved in one process.
+// Developer lab: A/B of arithmetic policies and ablations inside the N = 2^14 kernels (ntt14w.hpp), interleaved in one process.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o lab2 tools/ntt_lab2.hip      Run: ./lab2 [batch] [reps]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -6,14 +6,30 @@
 #include <vector>
 #include "../learn-fhe_amd/csrc/modmath.hpp"
 #include "../learn-fhe_amd/csrc/ntt_kernels.hpp"
-#include "../learn-fhe_amd/csrc/ntt14.hpp"
+#include "../learn-fhe_amd/csrc/ntt14w.hpp"
 using namespace fhe;
 
-struct DS60p0 : ArithDS<60> { static constexpr int PREFETCH = 0; };
-struct DS60p2 : ArithDS<60> { static constexpr int PREFETCH = 2; };
-struct DS60p8 : ArithDS<60> { static constexpr int PREFETCH = 8; };
+constexpr int N14_THREADS = w14::THREADS;
+constexpr size_t N14_LDS_BYTES = w14::LDS_BYTES;
+struct DSNoTw : ArithDS<60> {  // ablation: butterflies with a computed twiddle, no twiddle loads (wrong results, same work)
+    template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) { return uint4{k.ninv.x + (unsigned)idx, k.ninv.y, k.ninv.z ^ (unsigned)idx, k.ninv.w}; }
+};
+struct DSNone : ArithDS<60> {  // ablation: HBM traffic + exchanges only
+    static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
+    template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
+    template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &, int idx) { return uint4{(unsigned)idx, 1u, 2u, 3u}; }
+    static constexpr bool GS_FOLDS = false;
+    static __device__ constexpr bool ct_fold_at(int) { return false; }
+    static __device__ __forceinline__ u64 fold(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ u64 finish_inv(u64 x, const K &) { return x; }
+    template <int PH = 1> static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &) { X ^= 1; Y ^= 1; }
+};
 
+static int g_pgrid = 512;
+#define GRID(v) (batch)
 int main(int argc, char **argv) {
+    if (argc > 3) g_pgrid = atoi(argv[3]);
     const u64 q = 1152921504606748673ull;
     const int n = 1 << 14, batch = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 20;
     const int s = __builtin_ctzll(q - 1);
@@ -65,25 +81,25 @@ int main(int argc, char **argv) {
     u64 *d;
     hipMalloc(&d, h.size() * 8);
     typedef void (*kern_t)(u64 *, const ModDesc *, unsigned, unsigned, int);
-    struct V { const char *name; kern_t f, i; double sf, si; };
+    struct V { const char *name; kern_t f, i; double sf, si; int persistent; };
     V vs[] = {
-        {"PM60 (round-1 product)", ntt14_fwd_kernel<ArithPM<60>, false>, ntt14_inv_kernel<ArithPM<60>, false>, 0, 0},
-        {"DS60 (two-operand split)", ntt14_fwd_kernel<ArithDS<60>, false>, ntt14_inv_kernel<ArithDS<60>, false>, 0, 0},
-        {"DS60, no twiddle prefetch", ntt14_fwd_kernel<DS60p0, false>, ntt14_inv_kernel<DS60p0, false>, 0, 0},
-        {"DS60, prefetch <= 2", ntt14_fwd_kernel<DS60p2, false>, ntt14_inv_kernel<DS60p2, false>, 0, 0},
-        {"DS60, prefetch all", ntt14_fwd_kernel<DS60p8, false>, ntt14_inv_kernel<DS60p8, false>, 0, 0},
+        {"wave-local, PM60", ntt14w_fwd_kernel<ArithPM<60>, false>, ntt14w_inv_kernel<ArithPM<60>, false>, 0, 0, 1},
+        {"wave-local, DS60", ntt14w_fwd_kernel<ArithDS<60>, false>, ntt14w_inv_kernel<ArithDS<60>, false>, 0, 0, 1},
+        {"wave-local, Shoup", ntt14w_fwd_kernel<ArithShoup, false>, ntt14w_inv_kernel<ArithShoup, false>, 0, 0, 1},
+        {"wave-local DS60, no twiddle loads", ntt14w_fwd_kernel<DSNoTw, false>, ntt14w_inv_kernel<DSNoTw, false>, 0, 0, 1},
+        {"wave-local, no butterflies", ntt14w_fwd_kernel<DSNone, false>, ntt14w_inv_kernel<DSNone, false>, 0, 0, 1},
     };
     std::vector<u64> ref(h.size()), got(h.size());
     for (auto &v : vs) {
         hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
         hipFuncSetAttribute((const void *)v.i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
         hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         if (&v == &vs[0]) ref = got;
         size_t badf = 0, badi = 0;
         for (size_t i = 0; i < h.size(); ++i) badf += got[i] != ref[i];
-        hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
         hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < h.size(); ++i) badi += got[i] != h[i];
         hipError_t e = hipDeviceSynchronize();
@@ -103,9 +119,9 @@ int main(int argc, char **argv) {
             float f = 0, i = 0;
             for (int k = 0; k < 4; ++k) {
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
                 hipEventRecord(e1);
-                hipLaunchKernelGGL(v.i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
                 hipEventRecord(e2);
                 hipEventSynchronize(e2);
                 float a, b;
@@ -119,12 +135,12 @@ int main(int argc, char **argv) {
         printf("%-32s fwd %.4f ms %5.0f GB/s (%.3f of 8 TB/s) | inv %.4f ms %5.0f GB/s (%.3f)\n", v.name, v.sf / reps, bytes / (v.sf / reps * 1e-3) / 1e9,
                bytes / (v.sf / reps * 1e-3) / 8e12, v.si / reps, bytes / (v.si / reps * 1e-3) / 1e9, bytes / (v.si / reps * 1e-3) / 8e12);
 #ifdef NTT14_STAMPS
-    for (int vi = 0; vi < 3; ++vi) {   // where does a workgroup spend its life?
+    for (int vi : {0, 1}) {   // where does a workgroup spend its life?
         auto &v = vs[vi];
-        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(v.f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
         hipDeviceSynchronize();
         static unsigned long long hs[4096][16];
-        hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(w14::g_stamps), sizeof(hs));
         const char *names[] = {"issue loads", "pass0 (+load wait)", "xchg01", "pass1", "xchg12", "pass2", "xchg23", "pass3", "canon+store issue"};
         double sum[9] = {0}; double life = 0; int cnt = 0;
         unsigned long long t0 = ~0ull, t1 = 0;
@@ -137,6 +153,16 @@ int main(int argc, char **argv) {
         }
         printf("%s: stamps (s_memtime ticks, avg over %d workgroups; lifetime %.0f; kernel span %llu ticks)\n", v.name, cnt, life / cnt, t1 - t0);
         for (int p2 = 0; p2 < 9; ++p2) printf("  %-20s %8.0f (%4.1f%%)\n", names[p2], sum[p2] / cnt, 100.0 * sum[p2] / life);
+        {
+            double ck = 0; int c2 = 0; unsigned long long r0 = ~0ull, r1 = 0;
+            for (int b = 0; b < batch && b < 4096; ++b) {
+                if (hs[b][11] <= hs[b][10]) continue;
+                ck += double(hs[b][9] - hs[b][0]) / double(hs[b][11] - hs[b][10]) * 0.1; ++c2;
+                if (hs[b][10] < r0) r0 = hs[b][10];
+                if (hs[b][11] > r1) r1 = hs[b][11];
+            }
+            printf("  in-kernel clock %.3f GHz (s_memtime / s_memrealtime); first start -> last end %.1f us\n", ck / c2, double(r1 - r0) / 100.0);
+        }
     }
 #endif
     return 0;
