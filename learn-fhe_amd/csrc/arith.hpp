@@ -57,6 +57,23 @@ struct ModDesc {
     // w 2^32 mod q = b0 + b1 2^(pm_b-31); ds_pow = 2^(pm_b-31), read from memory so that the compiler keeps the multiply-add
     const uint4 *twd, *twdi;
     unsigned ds_pow;
+    // classical Barrett constants (dev_arith.hpp) for products of two VARIABLE operands inside a transform (fused ring products)
+    u64 bar_mu;
+    int bar_sh1, bar_sh2;
+};
+
+// Optional operands of a transform launch; all zero = the plain in-place transform.  Indices count sub-polynomials of the
+// launch (the 2^14 blocks of a larger ring count one each).
+//   src: sub-polynomial s is READ from src + (s % src_mod) * len instead of its own place (out-of-place forward; an inverse that
+//        shares its evaluation-domain input between several outputs);
+//   mul: (inverse only) every loaded evaluation is multiplied by the one at the same position of mul + mi * len,
+//        mi = (s / mul_div) * mul_period + s % mul_period: util/src/ring/fft/zq.rs:17 (`a[i] *= b[i]`) and ring/rns.rs:148-158
+//        fused into the load of the inverse transform.
+struct NttIo {
+    const u64 *src = nullptr;
+    unsigned src_mod = 1;
+    const u64 *mul = nullptr;
+    unsigned mul_div = 1, mul_period = 1;
 };
 
 struct ArithShoup {
@@ -67,11 +84,14 @@ struct ArithShoup {
         u64 ninv, ninv_s;
         int pb, prefix;
         TwPair ninv_w;  // n^-1 * twi[1] (whole rings only, pb = 0)
+        Barrett bar;
     };
     static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
         return K{D.q, 2 * D.q, as_global(D.tw), as_global(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix,
-                 TwPair{D.ninv_w[log_n_total], D.ninv_w_s[log_n_total]}};
+                 TwPair{D.ninv_w[log_n_total], D.ninv_w_s[log_n_total]}, Barrett{D.q, D.bar_mu, D.bar_sh1, D.bar_sh2}};
     }
+    // x y mod q for two canonical variable operands (fused pointwise products): canonical
+    static __device__ __forceinline__ u64 mulvar(u64 x, u64 y, const K &k) { return mulmod_barrett(x, y, k.bar); }
     // The LAST inverse layer of a whole ring with n^-1 folded in (util/src/ring/fft.rs:59-77: layer 0, then `* n_inv`): the
     // difference branch takes twi[1] n^-1 as its twiddle, only the sum branch still needs a product.  Canonical outputs.
     template <int PH = 1>
@@ -232,6 +252,8 @@ struct ArithPM {
     }
     // x mod~ q: < 2^B + 2^(64-B) c
     static __device__ __forceinline__ u64 fold1(u64 x, const PmK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
+    // x y mod~ q for two canonical variable operands (fused pointwise products): y is split like a twiddle; < q + eps
+    static __device__ __forceinline__ u64 mulvar(u64 x, u64 y, const K &k) { return pm_mul<B>(x, split(y), k.m); }
     // Forward butterfly without any reduction.  Values grow by at most 2q per layer; a multiplicand must stay below 2^63
     // and a sum below 2^64, which holds for 4 layers after a fold (inputs < q + eps -> multiplicands < 7q, outputs < 9q).
     static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &w, const K &k) {
@@ -359,6 +381,10 @@ struct ArithDS {
     // x mod~ q: < 2^B + (x >> B) c
     static __device__ __forceinline__ u64 fold1(u64 x, const DsK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
     static __device__ __forceinline__ u64 mul(u64 y, const uint4 &w, const DsK &m) { return fold1(mul_raw(y, w, m), m); }  // < q + 9c
+    // two VARIABLE canonical operands: the second one has no precomputed w 2^32 mod q, so this is the one-operand product
+    static __device__ __forceinline__ u64 mulvar(u64 x, u64 y, const K &k) {
+        return pm_mul<B>(x, ArithPM<B>::split(y), PmK{k.m.q, k.m.q2, k.m.q4, k.m.c, k.m.c2});
+    }
     // Forward butterfly: the multiplicand may be ANY 64-bit value, the product comes back below q + 9c, so a value grows by at
     // most 2q per layer and only the sums must stay below 2^64: (2^(64-B) - 2) / 2 layers between two folds (7 at 60 bits).
     static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &w, const K &k) {

@@ -36,6 +36,7 @@ int ctx_build_host(uint64_t q, fhe_ctx *c);  // returns FHE_* status
 // batched transforms over `batch` polynomials of degree 2^log_n; polynomial p uses descs[p % n_desc]
 // pm: common bit length b if EVERY descriptor is pseudo-Mersenne eligible with the same b (the N = 2^14 kernels then use
 // ArithPM<b> when instantiated), else 0
-int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0);
-int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0);
+// io (arith.hpp NttIo): optional out-of-place source / fused pointwise multiplier, indices in POLYNOMIALS of this launch
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0, NttIo io = NttIo());
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0, NttIo io = NttIo());
 }  // namespace fhe

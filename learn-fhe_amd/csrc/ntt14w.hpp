@@ -248,6 +248,16 @@ __device__ __forceinline__ void load_p3(u64 (&x)[32], const u64 *__restrict__ sr
         x[AB * 8 + j] = v.x; x[AB * 8 + j + 1] = v.y;
     }
 }
+// ... with the pointwise product of util/src/ring/fft/zq.rs:17 fused in: x <- src (.) mul, both canonical evaluations
+template <class A, int AB>
+__device__ __forceinline__ void load_mul_p3(u64 (&x)[32], const u64 *__restrict__ src, const u64 *__restrict__ mul, const typename A::K &k) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + (AB << 9) + j);
+        const ulonglong2 m = *reinterpret_cast<const ulonglong2 *>(mul + (AB << 9) + j);
+        x[AB * 8 + j] = A::mulvar(v.x, m.x, k); x[AB * 8 + j + 1] = A::mulvar(v.y, m.y, k);
+    }
+}
 
 // Forward stores.  A pass-3 lane owns 64 contiguous bytes per (i10 i9) value; stored as they stand, every 16-byte store
 // instruction would touch 32 lines (measured: the store side alone then runs at 4.4 TB/s instead of 5.0).  The finished
@@ -449,7 +459,7 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
 // PFX = false: whole 2^14 rings (pb = 0).  PFX = true: sub s is sub-transform s & (2^pb - 1) of polynomial s >> pb.
 template <class A, bool PFX>
 __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
-                                                                       unsigned subs, int pb) {
+                                                                       unsigned subs, int pb, NttIo io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
@@ -459,14 +469,15 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__rest
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
     u64 *g = data + (size_t(sub) << 14);
+    const u64 *gs = io.src ? io.src + (size_t(sub % io.src_mod) << 14) : g;
     u64 x[32];
-    w14::load_p0<0>(x, g, t); w14::load_p0<1>(x, g, t); w14::load_p0<2>(x, g, t); w14::load_p0<3>(x, g, t);
+    w14::load_p0<0>(x, gs, t); w14::load_p0<1>(x, gs, t); w14::load_p0<2>(x, gs, t); w14::load_p0<3>(x, gs, t);
     w14::fwd_one<A>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
 }
 
 template <class A, bool PFX>
 __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
-                                                                       unsigned subs, int pb) {
+                                                                       unsigned subs, int pb, NttIo io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
@@ -480,8 +491,15 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__rest
     w14::Tw7<A> d[2];
     w14::tw7_load<A, true, 0>(d[0], (w << 8) | lane, k);
     w14::tw7_load<A, true, 1>(d[1], (w << 8) | lane, k);
-    const u64 *src = g + ((w << 11) | (lane << 3));
-    w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
+    const int off = (w << 11) | (lane << 3);
+    const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << 14) : g) + off;
+    if (io.mul) {  // workgroup-uniform
+        const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << 14) + off;
+        w14::load_mul_p3<A, 0>(x, src, mul, k); w14::load_mul_p3<A, 1>(x, src, mul, k);
+        w14::load_mul_p3<A, 2>(x, src, mul, k); w14::load_mul_p3<A, 3>(x, src, mul, k);
+    } else {
+        w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
+    }
     w14::inv_one<A, PFX>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
 }
 

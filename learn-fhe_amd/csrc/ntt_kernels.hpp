@@ -80,11 +80,12 @@ __device__ __forceinline__ void exchange_sync() {
 template <class A, typename C, int LOG_N, int LOG_E, int L0, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>
 __device__ __forceinline__ void fwd_run(typename A::Elem (&x)[1 << LOG_E], int t, typename A::Elem *__restrict__ g, typename A::Elem *lds,
                                         bool active,
-                                        const typename A::K &k) {
+                                        const typename A::K &k, const typename A::Elem *__restrict__ gsrc = nullptr) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (L0 == 0) ? C::R0 : LOG_E;
     constexpr int G = E >> R;  // butterfly groups per thread in this pass
     constexpr bool first = (L0 == 0), last = (L0 + R == LOG_N);
+    if constexpr (first && !REGS_IO) { if (!gsrc) gsrc = g; }  // out-of-place forward: read there, write here
     // load
 #pragma unroll
     for (int gg = 0; gg < G; ++gg) {
@@ -93,7 +94,7 @@ __device__ __forceinline__ void fwd_run(typename A::Elem (&x)[1 << LOG_E], int t
         for (int r = 0; r < (1 << R); ++r) {
             const int i = pass_index<LOG_N, L0, R>(grp, r);
             if constexpr (first) {
-                if constexpr (!REGS_IO) x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
+                if constexpr (!REGS_IO) x[gg * (1 << R) + r] = active ? gload(gsrc, i) : 0;
             } else {
                 x[gg * (1 << R) + r] = lds[lds_phys(i)];
             }
@@ -161,7 +162,7 @@ __device__ __forceinline__ void fwd_run(typename A::Elem (&x)[1 << LOG_E], int t
 // (s >> pb) % n_desc) and is its sub-transform number s & (2^pb - 1).  pb = 0: plain transforms.
 template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = false>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_kernel(
-    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg, NttIo io) {
     const int pb = PFX ? pb_arg : 0;  // PFX = false: every twiddle index folds to a constant expression
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
-    fwd_run<A, C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, k);
+    fwd_run<A, C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, k, io.src ? io.src + size_t(poly % io.src_mod) * C::N : nullptr);
     if constexpr (C::P > 1 && !DIRECT) {
         // the canonical image sits in LDS: stream it out with consecutive lanes on consecutive addresses
         if (active) {
@@ -194,9 +195,11 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
 template <class A, typename C, int LOG_N, int LOG_E, int LEND, bool REGS_IO = false, bool WAVE = false, bool DIRECT = false>  // layers [L0, LEND)
 __device__ __forceinline__ void inv_run(typename A::Elem (&x)[1 << LOG_E], int t, typename A::Elem *__restrict__ g, typename A::Elem *lds,
                                         bool active,
-                                        const typename A::K &k) {
+                                        const typename A::K &k, const typename A::Elem *__restrict__ gsrc = nullptr,
+                                        const typename A::Elem *__restrict__ gmul = nullptr) {
     constexpr int E = 1 << LOG_E;
     constexpr int R = (LEND == C::R0) ? C::R0 : LOG_E;
+    if constexpr (LEND == LOG_N && !REGS_IO) { if (!gsrc) gsrc = g; }
     constexpr int L0 = LEND - R;
     constexpr int G = E >> R;
     constexpr bool final_pass = (L0 == 0);
@@ -213,12 +216,17 @@ __device__ __forceinline__ void inv_run(typename A::Elem (&x)[1 << LOG_E], int t
 #ifdef FHE_ABLATE_NO_GLOBAL
                     x[r] = gload(g, i); x[r + 1] = gload(g, i + 1);
 #else
-                    const ulonglong2 v = active ? *reinterpret_cast<const ulonglong2 *>(g + i) : ulonglong2{0, 0};
+                    const ulonglong2 v = active ? *reinterpret_cast<const ulonglong2 *>(gsrc + i) : ulonglong2{0, 0};
                     x[r] = v.x; x[r + 1] = v.y;
+                    if (gmul && active) {
+                        const ulonglong2 m = *reinterpret_cast<const ulonglong2 *>(gmul + i);
+                        x[r] = A::mulvar(v.x, m.x, k); x[r + 1] = A::mulvar(v.y, m.y, k);
+                    }
 #endif
                 }
             } else if constexpr (C::P == 1) {
-                x[gg * (1 << R) + r] = active ? gload(g, i) : 0;
+                x[gg * (1 << R) + r] = active ? gload(gsrc, i) : 0;
+                if (gmul && active) x[gg * (1 << R) + r] = A::mulvar(x[gg * (1 << R) + r], gload(gmul, i), k);
             } else {
                 x[gg * (1 << R) + r] = lds[lds_phys(i)];
             }
@@ -255,7 +263,7 @@ __device__ __forceinline__ void inv_run(typename A::Elem (&x)[1 << LOG_E], int t
 
 template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false, bool DIRECT = true>
 __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_kernel(
-    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg) {
+    u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned subs, int pb_arg, NttIo io) {
     const int pb = PFX ? pb_arg : 0;
     using C = NttCfg<LOG_N, LOG_E, PPW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -268,21 +276,26 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_inv_
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
+    const u64 *gsrc = io.src ? io.src + size_t(poly % io.src_mod) * C::N : g;
+    const u64 *gmul = io.mul ? io.mul + (size_t(poly / io.mul_div) * io.mul_period + poly % io.mul_period) * C::N : nullptr;
     if constexpr (C::P > 1 && !DIRECT) {
 #pragma unroll
         for (int kk = 0; kk < C::E; ++kk) {
             const int i = t + C::T * kk;
-            lds[lds_phys(i)] = active ? gload(g, i) : 0;
+            u64 v = active ? gload(gsrc, i) : 0;
+            if (gmul && active) v = A::mulvar(v, gload(gmul, i), k);
+            lds[lds_phys(i)] = v;
         }
         __syncthreads();
     }
-    inv_run<A, C, LOG_N, LOG_E, LOG_N, false, false, DIRECT>(x, t, g, lds, active, k);
+    inv_run<A, C, LOG_N, LOG_E, LOG_N, false, false, DIRECT>(x, t, g, lds, active, k, gsrc, gmul);
 }
 
 // Opening radix-2^PB pass of a ring of degree 2^log_n (layers 0..PB-1 across the 2^PB blocks), one thread per
 // column; leaves canonical values.  Followed by ntt_fwd_kernel<log_n - PB, ...> with pb = PB.
 template <int PB>
-__global__ void ntt_big_fwd_pass(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned batch, int log_n) {
+__global__ void ntt_big_fwd_pass(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc, unsigned batch, int log_n,
+                                 const u64 *__restrict__ src, unsigned src_mod) {
     const int lc = log_n - PB;  // log2 of the column count
     const size_t total = size_t(batch) << lc;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
@@ -291,9 +304,10 @@ __global__ void ntt_big_fwd_pass(u64 *__restrict__ data, const ModDesc *__restri
         const ModDesc &D = descs[poly % n_desc];
         const u64 q = D.q, q2 = 2 * q;
         u64 *g = data + (size_t(poly) << log_n) + low;
+        const u64 *gs = src ? src + (size_t(poly % src_mod) << log_n) + low : g;
         u64 x[1 << PB];
 #pragma unroll
-        for (int r = 0; r < (1 << PB); ++r) x[r] = g[size_t(r) << lc];
+        for (int r = 0; r < (1 << PB); ++r) x[r] = gs[size_t(r) << lc];
         const ArithShoup::K k = ArithShoup::make(D, log_n, 0, 0);
         ct_net<ArithShoup, 0, PB, 0, (1 << PB)>(x, 0, k);
 #pragma unroll

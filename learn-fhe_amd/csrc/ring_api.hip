@@ -41,7 +41,7 @@ hipError_t set_max_lds(const void *kernel, int bytes) {
 }
 
 template <class A, int LOG_N, int LOG_E, int PPW, bool PFX = false>
-int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st) {
+int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     using C = fhe::NttCfg<LOG_N, LOG_E, PPW>;
     // measured on MI355X (tools/ntt_lab.hip): staging through LDS wins for the forward stores, direct 16-byte loads win
     // for the inverse
@@ -49,7 +49,7 @@ int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a,
     if (C::LDS_BYTES > 64 * 1024)
         HIP_TRY(set_max_lds((const void *)k, (int)C::LDS_BYTES));
     unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
@@ -57,27 +57,27 @@ int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a,
 // (LOG_N -> LOG_E, PPW): 16 coefficients per thread from N = 128 up; small rings pack many polynomials
 // into one 64..256-thread workgroup
 template <class A>
-int dispatch_small(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, hipStream_t st) {
+int dispatch_small(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, hipStream_t st, fhe::NttIo io) {
     switch (log_n) {
-        case 1: return launch_gen<A, 1, 1, 64>(inv, d, nd, a, subs, 0, st);
-        case 2: return launch_gen<A, 2, 2, 64>(inv, d, nd, a, subs, 0, st);
-        case 3: return launch_gen<A, 3, 3, 64>(inv, d, nd, a, subs, 0, st);
-        case 4: return launch_gen<A, 4, 4, 64>(inv, d, nd, a, subs, 0, st);
-        case 5: return launch_gen<A, 5, 3, 16>(inv, d, nd, a, subs, 0, st);
-        case 6: return launch_gen<A, 6, 3, 16>(inv, d, nd, a, subs, 0, st);
-        case 7: return launch_gen<A, 7, 4, 16>(inv, d, nd, a, subs, 0, st);
-        case 8: return launch_gen<A, 8, 4, 16>(inv, d, nd, a, subs, 0, st);
-        case 9: return launch_gen<A, 9, 4, 8>(inv, d, nd, a, subs, 0, st);
+        case 1: return launch_gen<A, 1, 1, 64>(inv, d, nd, a, subs, 0, st, io);
+        case 2: return launch_gen<A, 2, 2, 64>(inv, d, nd, a, subs, 0, st, io);
+        case 3: return launch_gen<A, 3, 3, 64>(inv, d, nd, a, subs, 0, st, io);
+        case 4: return launch_gen<A, 4, 4, 64>(inv, d, nd, a, subs, 0, st, io);
+        case 5: return launch_gen<A, 5, 3, 16>(inv, d, nd, a, subs, 0, st, io);
+        case 6: return launch_gen<A, 6, 3, 16>(inv, d, nd, a, subs, 0, st, io);
+        case 7: return launch_gen<A, 7, 4, 16>(inv, d, nd, a, subs, 0, st, io);
+        case 8: return launch_gen<A, 8, 4, 16>(inv, d, nd, a, subs, 0, st, io);
+        case 9: return launch_gen<A, 9, 4, 8>(inv, d, nd, a, subs, 0, st, io);
         default: return FHE_ERR_UNSUPPORTED;
     }
 }
 template <class A>
-int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
+int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     switch (log_n) {
-        case 10: return launch_gen<A, 10, 4, 4>(inv, d, nd, a, subs, 0, st);
-        case 11: return launch_gen<A, 11, 4, 2>(inv, d, nd, a, subs, 0, st);
-        case 12: return launch_gen<A, 12, 4, 1>(inv, d, nd, a, subs, 0, st);
-        case 13: return launch_gen<A, 13, 4, 1>(inv, d, nd, a, subs, 0, st);
+        case 10: return launch_gen<A, 10, 4, 4>(inv, d, nd, a, subs, 0, st, io);
+        case 11: return launch_gen<A, 11, 4, 2>(inv, d, nd, a, subs, 0, st, io);
+        case 12: return launch_gen<A, 12, 4, 1>(inv, d, nd, a, subs, 0, st, io);
+        case 13: return launch_gen<A, 13, 4, 1>(inv, d, nd, a, subs, 0, st, io);
         default: return FHE_ERR_UNSUPPORTED;
     }
 }
@@ -88,31 +88,31 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // 0.320 -- the inverse's per-lane twiddles are needed first, while the coefficients are still on their way from HBM, and the
 // 16-byte form makes that wait longer than the instructions it saves).
 template <class AF, class AI>
-int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st) {
+int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? fhe::ntt14w_inv_kernel<AI, true> : fhe::ntt14w_fwd_kernel<AF, true>)
                 : (inv ? fhe::ntt14w_inv_kernel<AI, false> : fhe::ntt14w_fwd_kernel<AF, false>);
     HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::LDS_BYTES));
-    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::THREADS), fhe::w14::LDS_BYTES, st, a, d, nd, (unsigned)subs, pb);
+    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::THREADS), fhe::w14::LDS_BYTES, st, a, d, nd, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
 
 // pm = common bit length of pseudo-Mersenne eligible moduli for which kernels are instantiated (60, 54), else 0
-int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
+int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
-    if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st);
-    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st)
-                                     : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st);
-    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st)
-                                     : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st);
-    return log_n == 14 ? launch14<fhe::ArithShoup, fhe::ArithShoup>(inv, d, nd, a, subs, pb, st)
-                       : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st);
+    if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st, io);
+    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st, io)
+                                     : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st, io);
+    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st, io)
+                                     : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st, io);
+    return log_n == 14 ? launch14<fhe::ArithShoup, fhe::ArithShoup>(inv, d, nd, a, subs, pb, st, io)
+                       : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st, io);
 }
-int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
-    return sub_transform(false, d, nd, a, log_n, subs, pb, pm, st);
+int sub_fwd(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
+    return sub_transform(false, d, nd, a, log_n, subs, pb, pm, st, io);
 }
-int sub_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st) {
-    return sub_transform(true, d, nd, a, log_n, subs, pb, pm, st);
+int sub_inv(const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
+    return sub_transform(true, d, nd, a, log_n, subs, pb, pm, st, io);
 }
 
 inline unsigned pass_grid(size_t total) {
@@ -124,25 +124,29 @@ inline unsigned pass_grid(size_t total) {
 
 namespace fhe {
 
-// rings above 2^14 do not fit one workgroup's LDS: one radix-2^pb pass over HBM + 2^pb sub-transforms of 2^14
-int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm) {
-    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st);
+// rings above 2^14 do not fit one workgroup's LDS: one radix-2^pb pass over HBM + 2^pb sub-transforms of 2^14.
+// io counts POLYNOMIALS; the sub-transform launches take it in 2^14 blocks.
+int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
+    if (io.mul) return FHE_ERR_INVALID;  // the pointwise multiplier belongs to the inverse
+    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st, io);
     const int pb = log_n - 14;
     const size_t cols = batch << 14;
-    switch (pb) {
-        case 1: hipLaunchKernelGGL(ntt_big_fwd_pass<1>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
-        case 2: hipLaunchKernelGGL(ntt_big_fwd_pass<2>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
-        case 3: hipLaunchKernelGGL(ntt_big_fwd_pass<3>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n); break;
+    switch (pb) {  // the opening pass reads the source, everything after it runs in place
+        case 1: hipLaunchKernelGGL(ntt_big_fwd_pass<1>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n, io.src, io.src_mod); break;
+        case 2: hipLaunchKernelGGL(ntt_big_fwd_pass<2>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n, io.src, io.src_mod); break;
+        case 3: hipLaunchKernelGGL(ntt_big_fwd_pass<3>, dim3(pass_grid(cols)), dim3(256), 0, st, a, descs, n_desc, (unsigned)batch, log_n, io.src, io.src_mod); break;
         default: return FHE_ERR_UNSUPPORTED;
     }
     HIP_TRY(hipGetLastError());
-    return sub_fwd(descs, n_desc, a, 14, batch << pb, pb, pm, st);
+    return sub_fwd(descs, n_desc, a, 14, batch << pb, pb, pm, st, NttIo());
 }
 
-int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm) {
-    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st);
+int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
+    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st, io);
     const int pb = log_n - 14;
-    int rc = sub_inv(descs, n_desc, a, 14, batch << pb, pb, pm, st);
+    NttIo sub_io = io;  // polynomial counts -> 2^14 block counts
+    sub_io.src_mod = io.src_mod << pb; sub_io.mul_div = io.mul_div << pb; sub_io.mul_period = io.mul_period << pb;
+    int rc = sub_inv(descs, n_desc, a, 14, batch << pb, pb, pm, st, sub_io);
     if (rc != FHE_OK) return rc;
     const size_t cols = batch << 14;
     switch (pb) {
@@ -283,6 +287,7 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
             c->h_desc.ninv_w[k] = c->ninv_w[k]; c->h_desc.ninv_w_s[k] = c->ninv_w_s[k];
         }
         c->h_desc.one_s = fhe::shoup(1, q);
+        c->h_desc.bar_mu = c->barrett.mu; c->h_desc.bar_sh1 = c->barrett.sh1; c->h_desc.bar_sh2 = c->barrett.sh2;
         if (e == hipSuccess) e = hipMalloc(&c->d_desc, sizeof(fhe::ModDesc));
         if (e == hipSuccess) e = hipMemcpy(c->d_desc, &c->h_desc, sizeof(fhe::ModDesc), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -416,16 +421,29 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
     const int log_n = ilog2(n);
     Mirror ma(a, count, mem, true, st);
     if (ma.rc != FHE_OK) return ma.rc;
-    // b is const: transform a scratch copy (the reference allocates one too, fft/zq.rs:21-25)
+    // util/src/ring/fft/zq.rs:14-19 in three launches and 56 N bytes of HBM traffic instead of the reference's shape (copy of b,
+    // two in-place transforms, a pointwise pass, the inverse: 88 N): b is transformed OUT OF PLACE into the scratch the reference
+    // allocates too (fft/zq.rs:21-25), and the pointwise product rides on the load of the inverse transform.
     StreamWs ws(count * sizeof(u64), st);
     if (ws.rc != FHE_OK) return ws.rc;
     u64 *tb = ws.as<u64>();
-    hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (n > 1 && mem == FHE_MEM_DEVICE) {
+        fhe::NttIo src_b;
+        src_b.src = (const u64 *)b; src_b.src_mod = (unsigned)batch;
+        rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, tb, log_n, batch, st, ctx->pm_b, src_b);
+    } else {  // host operand (or n = 1): the copy is the upload
+        hipMemcpyKind kind = mem == FHE_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+        if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, tb, log_n, batch, st);
+    }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, ma.d, log_n, batch, st);
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, tb, log_n, batch, st);
-    if (rc == FHE_OK) rc = launch_pointwise(ctx, ma.d, tb, count, st);
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_device(ctx, ma.d, log_n, batch, st);
+    if (rc == FHE_OK && n > 1) {
+        fhe::NttIo mul_b;
+        mul_b.mul = tb; mul_b.mul_div = (unsigned)batch; mul_b.mul_period = (unsigned)batch;
+        rc = fhe::ntt_inv_multi(ctx->d_desc, 1, ma.d, log_n, batch, st, ctx->pm_b, mul_b);
+    } else if (rc == FHE_OK) {
+        rc = launch_pointwise(ctx, ma.d, tb, count, st);  // n = 1: `a[0] *= b[0]`
+    }
     if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;  // tb is released in stream order
 }

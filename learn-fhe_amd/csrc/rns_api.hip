@@ -344,13 +344,18 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
-    if (rc == FHE_OK) {
+    // ksk.b * a~ and ksk.a * a~ (ring/rns.rs:148-158) ride on the load of ONE inverse launch over the 2 * batch * lk output
+    // limbs: output limb s reads a~ limb s % (batch lk) and key limb (s / (batch lk)) lk + s % lk (d_kb and d_ka are adjacent)
+    if (rc == FHE_OK && n > 1) {
+        fhe::NttIo io;
+        io.src = ext; io.src_mod = (unsigned)(batch * lk);
+        io.mul = key->d_kb; io.mul_div = (unsigned)(batch * lk); io.mul_period = (unsigned)lk;
+        rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st, r->all_pm, io);
+    } else if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, PointwiseGrid(n, batch * lk).g, dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
                            (const u64 *)key->d_ka, pb, pa, (unsigned)n, (unsigned)lk, batch * lk, (const fhe::Barrett *)r->d_barrett);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
-    // pb and pa are adjacent: one inverse launch over 2 * batch * lk polynomials
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st, r->all_pm);
     if (rc == FHE_OK) {
         launch_rescale(pb, lk * n, mb.d, L * n, mb.d, L * n, n, batch, r->resc, st);
         launch_rescale(pa, lk * n, ma.d, L * n, nullptr, 0, n, batch, r->resc, st);

@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < n && batch > 3; ++i) { h[i] = q - 1; h[n + i] = 0; h[2 * n + i] = (i & 1) ? q - 1 : 0; }
     u64 *d;
     hipMalloc(&d, h.size() * 8);
-    typedef void (*kern_t)(u64 *, const ModDesc *, unsigned, unsigned, int);
+    typedef void (*kern_t)(u64 *, const ModDesc *, unsigned, unsigned, int, NttIo);
     struct V { const char *name; kern_t f, i; double sf, si; int persistent; };
     V vs[] = {
         {"wave-local, PM60", ntt14w_fwd_kernel<ArithPM<60>, false>, ntt14w_inv_kernel<ArithPM<60>, false>, 0, 0, 1},
@@ -94,12 +94,12 @@ int main(int argc, char **argv) {
         hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
         hipFuncSetAttribute((const void *)v.i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N14_LDS_BYTES);
         hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
         hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         if (&v == &vs[0]) ref = got;
         size_t badf = 0, badi = 0;
         for (size_t i = 0; i < h.size(); ++i) badf += got[i] != ref[i];
-        hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
         hipMemcpy(got.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < h.size(); ++i) badi += got[i] != h[i];
         hipError_t e = hipDeviceSynchronize();
@@ -109,8 +109,8 @@ int main(int argc, char **argv) {
     hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
     // pre-heat: ~100 ms of the first variant
     for (int r = 0; r < 150; ++r) {
-        hipLaunchKernelGGL(vs[0].f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
-        hipLaunchKernelGGL(vs[0].i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        hipLaunchKernelGGL(vs[0].f, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
+        hipLaunchKernelGGL(vs[0].i, dim3(batch), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
     }
     hipDeviceSynchronize();
     for (int r = 0; r < reps; ++r)
@@ -119,9 +119,9 @@ int main(int argc, char **argv) {
             float f = 0, i = 0;
             for (int k = 0; k < 4; ++k) {
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
                 hipEventRecord(e1);
-                hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+                hipLaunchKernelGGL(v.i, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
                 hipEventRecord(e2);
                 hipEventSynchronize(e2);
                 float a, b;
@@ -137,7 +137,7 @@ int main(int argc, char **argv) {
 #ifdef NTT14_STAMPS
     for (int vi : {0, 1}) {   // where does a workgroup spend its life?
         auto &v = vs[vi];
-        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0);
+        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
         hipDeviceSynchronize();
         static unsigned long long hs[4096][16];
         hipMemcpyFromSymbol(hs, HIP_SYMBOL(w14::g_stamps), sizeof(hs));
