@@ -5,14 +5,18 @@ Metric (BASELINE.json): NTTs/sec at N = 2^14, q ~ 60-bit.  Workload (`configs[1]
 inverse negacyclic NTT, N = 2^14, q = 1152921504606748673, batch = 4096 polynomials per GPU resident in HBM.
 One "step" = forward over the whole batch, then inverse over the whole batch (2 * 4096 transforms).
 Multi-GPU: one process per GPU (torch.distributed / RCCL), polynomials sharded, no data-path collective,
-weak scaling (4096 polynomials per GPU).
+weak scaling (4096 polynomials per GPU).  `python bench.py --gpus N` without a launcher starts the N ranks itself.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event
-timed on the launch stream) and, at N = 1, `cpu_baseline` (the oracle's C restatement timed on host cores).
+timed on the launch stream), `verified` (the timed buffers are checked: round trip == identity over the whole run,
+forward == the CPU oracle on 64 polynomials) and, at N = 1, `cpu_baseline` (the oracle's C restatement timed on host
+cores).  Secondary blocks (`ntt_mul`, `fhew`, `ckks`, `tfhe`) carry their own roofline (SURVEY.md 8(d) bytes) and CPU figure.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +29,17 @@ LOG_N = 14
 BATCH = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 ALGO_BYTES_PER_NTT = 16 * (1 << LOG_N)  # 8N read + 8N write
+FWD_KERNEL = "ntt14w_fwd_kernel<ArithDS<60>, false> (forward transform)"
+
+
+def roof(units_per_sec, bytes_per_unit, kernel, note=None):
+    """achieved = algorithmic bytes per unit x units per second, against the 8 TB/s HBM peak."""
+    gbs = units_per_sec * bytes_per_unit / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "algorithmic_bytes_per_unit": bytes_per_unit, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS}
+    if note:
+        r["note"] = note
+    return r
 
 
 def cpu_baseline(sample_per_thread=512, reps=4):
@@ -66,12 +81,22 @@ def _timeit(torch, fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
-    """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
-    rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
-    N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident; and the
-    whole gate bootstrap around it (bootstrapping.rs:149-155: mod switch, LWE key switch over 2^16 with base 2^4 d = 4
-    as in the reference's parameter sets, odd mod switch, blind rotation, sample extract)."""
+def ntt_mul_bench(torch, F, dev, local_rank, batch, reps=20):
+    """`Rq * Rq` (util/src/ring/fft/zq.rs:14-19) on cfg2's ring: 3 launches, 24 N algorithmic bytes (read a, b; write c)."""
+    n = 1 << LOG_N
+    ctx = F.NttContext(Q, device=local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12)
+    a = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
+    b = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
+    dt = _timeit(torch, lambda: ctx.mul_(a, b, n), reps)
+    out = {"workload": "ring product a *= b, N=2^14, q=%d, batch=%d" % (Q, batch), "products_per_sec": batch / dt,
+           "hbm_traffic_bytes_per_product_by_construction": 56 * n}
+    out["roofline"] = roof(batch / dt, 24 * n, "ntt14w_fwd_kernel x2 + ntt14w_inv_kernel (pointwise product fused into its load)")
+    return out
+
+
+def fhew_setup(torch, F, dev, local_rank):
     q, n, log_b, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 100
     q_ks, kb, kd = 1 << 16, 4, 4
     ctx = F.NttContext(q, device=local_rank)
@@ -81,22 +106,47 @@ def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
     brk = F.GadgetKey(ctx, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n, rgsw=True)
     ak = F.GadgetKey(ctx, log_b, d, rnd(w + 1, d, n), rnd(w + 1, d, n), n, rgsw=False)
     bk = F.BootstrapKey(ctx, brk, ak, F.ak_t(n, w), w)
-    ksk_a, ksk_b = rnd(kd * n, n_lwe, m=q_ks), rnd(kd * n, m=q_ks)
-    f = rnd(n)
+    return dict(q=q, n=n, log_b=log_b, d=d, w=w, n_lwe=n_lwe, q_ks=q_ks, kb=kb, kd=kd, ctx=ctx, gen=gen, rnd=rnd, brk=brk, ak=ak, bk=bk,
+                ksk_a=rnd(kd * n, n_lwe, m=q_ks), ksk_b=rnd(kd * n, m=q_ks), f=rnd(n))
+
+
+def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
+    """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
+    rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
+    N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident; and the
+    whole gate bootstrap around it (bootstrapping.rs:149-155: mod switch, LWE key switch over 2^16 with base 2^4 d = 4
+    as in the reference's parameter sets, odd mod switch, blind rotation, sample extract)."""
+    S = fhew_setup(torch, F, dev, local_rank)
+    q, n, d, n_lwe, gen, rnd, bk, brk = S["q"], S["n"], S["d"], S["n_lwe"], S["gen"], S["rnd"], S["bk"], S["brk"]
     out = {"workload": "cfg3: LMKCDEY blind rotation N=2^10 q=%d log_b=6 d=9 n_lwe=100 w=10; gate = + LWE key switch "
                        "q_ks=2^16 (4,4), mod switches, sample extract" % q}
+    n_auto = None
     for batch in batches:
         lwe_a = torch.randint(0, n, (batch, n_lwe), dtype=torch.int64, device=dev, generator=gen) * 2 + 1
         lwe_b = torch.randint(0, 2 * n, (batch,), dtype=torch.int64, device=dev, generator=gen)
-        dt = _timeit(torch, lambda: bk.blind_rotate(lwe_a, lwe_b, f), reps)
+        dt = _timeit(torch, lambda: bk.blind_rotate(lwe_a, lwe_b, S["f"]), reps)
         out["blind_rotations_per_sec_batch%d" % batch] = batch / dt
+        if batch == 1024:
+            # automorphism key switches per blind rotation: data dependent (bootstrapping.rs:172-231); counted on 64 ciphertexts of this batch
+            _, _, sched = bk.blind_rotate(lwe_a[:64].contiguous(), lwe_b[:64].contiguous(), S["f"], want_schedule=True)
+            n_auto = sum(sum(1 for kind, _ in ops if kind == "ak") for ops in sched) / float(len(sched))
     batch = 1024
     ct_a, ct_b = rnd(batch, n), rnd(batch)
-    dt = _timeit(torch, lambda: bk.bootstrap(q_ks, kb, kd, ksk_a, ksk_b, f, ct_a, ct_b, addend=q // 8), reps)
+    dt = _timeit(torch, lambda: bk.bootstrap(S["q_ks"], S["kb"], S["kd"], S["ksk_a"], S["ksk_b"], S["f"], ct_a, ct_b, addend=q // 8), reps)
     out["gate_bootstraps_per_sec_batch%d" % batch] = batch / dt
     ca, cb = rnd(4096, n), rnd(4096, n)
     dt = _timeit(torch, lambda: brk.external_product_(0, ca, cb), 10)
     out["external_products_per_sec_batch4096"] = 4096 / dt
+    ep_bytes = (4 * d + 4) * 8 * n                      # SURVEY.md 8(d): ct in + 2d rows x (a, b) + ct out
+    ks_bytes = (2 * d + 4) * 8 * n
+    out["roofline_external_product"] = roof(4096 / dt, ep_bytes, "external_product_kernel<WaveRing<10>, ArithPM<54>> (fused decompose -> NTT -> accumulate)",
+                                            "key rows (288 KiB per RGSW ciphertext) are L2 / Infinity-Cache hits: the kernel is bound by VALU issue, not HBM")
+    if n_auto is not None:
+        br_bytes = n_lwe * ep_bytes + n_auto * ks_bytes
+        out["automorphism_key_switches_per_blind_rotation"] = n_auto
+        out["roofline"] = roof(out["blind_rotations_per_sec_batch1024"], br_bytes, "blind_rotate_kernel<WaveRing<10>, ArithPM<54>> (batch 1024)",
+                               "%d external products x %d B + %.1f automorphism key switches x %d B per blind rotation; keys cache resident"
+                               % (n_lwe, ep_bytes, n_auto, ks_bytes))
     return out
 
 
@@ -119,39 +169,47 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
         cb, ca = limbs(qs, b), limbs(qs, b)
         dt = _timeit(torch, lambda: key.key_switch_(cb, ca), reps)
         out["key_switches_per_sec_batch%d" % b] = b / dt
+    # ct in 2L 8N + ksk 2(L+K) 8N + ct out 2L 8N = 16 MiB at cfg4
+    out["roofline"] = roof(out["key_switches_per_sec_batch%d" % (8 * batch)], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
+                           "rns_extend + ntt_big_fwd_pass + ntt14w_fwd + ntt14w_inv (ksk products fused) + ntt_big_inv_pass + rns_rescale x2",
+                           "rings above 2^14 pay a second HBM round trip per transform (radix-2 pass + 2^14 sub-transforms)")
     return out
 
 
-def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
-    """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
-    bootstrapping.rs:139-165) at N = 2^10, k = 1: mod switch, n_lwe = 630 CMUXes (base 2^7, d = 3 -- the reference ships
-    no N = 2^10 parameter set; these are the usual ones for that ring), sample extract, TLWE key switch (base 2^4, d = 5
-    as in the reference's test).  Exact torus arithmetic (CRT over three 30-bit primes at this shape), uniform-random keys."""
+def tfhe_setup(torch, F, dev, local_rank, batch):
     n, n_lwe, log_b, d, ks_lb, ks_d = 1024, 630, 7, 3, 4, 5
     t = F.TorusContext(device=local_rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
     rnd = lambda *shape: torch.randint(-(1 << 63), (1 << 63) - 1, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
     key = F.TggswKey(t, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n)
-    ksa, ksb = rnd(n * ks_d, n_lwe), rnd(n * ks_d)
-    v = rnd(n)
-    a_raw, b_raw = rnd(batch, n_lwe), rnd(batch)
-
-    def gate():
-        at, bt = F.TorusContext.mod_switch(a_raw, n), F.TorusContext.mod_switch(b_raw, n)
-        oa, ob = key.blind_rotate(at, bt, v)
-        ea, eb = F.tglwe_sample_extract(oa, ob, n, 0)
-        return F.tlwe_key_switch(ks_lb, ks_d, ksa, ksb, ea, eb, n, n_lwe)
-
-    dt = _timeit(torch, gate, reps)
-    return {"workload": "cfg5 (one GPU's share): TFHE gate bootstrap N=2^10 k=1 n_lwe=630 (7,3) ks (4,5), batch=%d" % batch,
-            "gate_bootstraps_per_sec": batch / dt}
+    return dict(n=n, n_lwe=n_lwe, log_b=log_b, d=d, ks_lb=ks_lb, ks_d=ks_d, t=t, key=key, ksa=rnd(n * ks_d, n_lwe), ksb=rnd(n * ks_d), v=rnd(n),
+                a_raw=rnd(batch, n_lwe), b_raw=rnd(batch))
 
 
-def cpu_fhew_baseline():
-    """cfg3 blind rotation of ONE ciphertext on one host core with the oracle's C restatement (the reference is single-threaded)."""
+def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
+    """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
+    bootstrapping.rs:78-104) at N = 2^10, k = 1, through the single-call gate fhe_tfhe_bootstrap: mod switch, n_lwe = 630 CMUXes
+    (base 2^7, d = 3 -- the reference ships no N = 2^10 parameter set; these are the usual ones for that ring), sample extract,
+    TLWE key switch (base 2^4, d = 5 as in the reference's test).  Exact torus arithmetic (CRT over three 30-bit primes at this
+    shape), uniform-random keys."""
+    S = tfhe_setup(torch, F, dev, local_rank, batch)
+    dt = _timeit(torch, lambda: S["key"].bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"]), reps)
+    out = {"workload": "cfg5 (one GPU's share): TFHE gate bootstrap N=2^10 k=1 n_lwe=630 (7,3) ks (4,5), batch=%d" % batch,
+           "gate_bootstraps_per_sec": batch / dt}
+    cmux_bytes = (4 * S["d"] + 4) * 8 * S["n"]  # as an RGSW external product: ct in + 2d rows x 2 + ct out
+    out["roofline"] = roof(batch / dt, S["n_lwe"] * cmux_bytes, "torus30_blind_rotate_kernel<TorusRing30<10>> (630 CMUXes in one launch)",
+                           "%d CMUXes x %d B per gate (TLWE key switch not counted); TGGSW rows are cache hits: bound by VALU issue" % (S["n_lwe"], cmux_bytes))
+    return out
+
+
+def cpu_secondary_baselines():
+    """cfg3 / cfg4 / cfg5 units on host cores with the oracle's C restatement (kind "port"): one core each (the reference is
+    single-threaded), bounded samples."""
     import numpy as np
     from oracle import cref
+    out = {}
+    # cfg3: one blind rotation
     q, n, log_b, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 100
     rng = np.random.Generator(np.random.PCG64(6))
     brk = rng.integers(0, q, size=(n_lwe, 2, 2 * d, n), dtype=np.uint64)
@@ -168,64 +226,161 @@ def cpu_fhew_baseline():
     t0 = time.perf_counter()
     cref.blind_rotate(q, n, w, log_b, d, log_b, d, brk, ak, ts, f, lwe_a, 7)
     dt = time.perf_counter() - t0
-    return {"blind_rotations_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg3 blind rotation"}
+    out["fhew"] = {"blind_rotations_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg3 blind rotation"}
+    # cfg4: one CKKS key switch
+    n4, big_l = 1 << 15, 8
+    primes = cref.two_adic_primes(60, 16, 2 * big_l)
+    qs, ps = primes[:big_l], primes[big_l:]
+    limbs = lambda ms: np.stack([rng.integers(0, m, size=n4, dtype=np.uint64) for m in ms])  # noqa: E731
+    kb, ka, cb, ca = limbs(qs + ps), limbs(qs + ps), limbs(qs), limbs(qs)
+    for m in qs + ps:
+        cref.ntt_fwd(m, np.zeros(n4, dtype=np.uint64), n4)  # twiddle set-up
+    t0 = time.perf_counter()
+    cref.ckks_key_switch(qs, ps, kb, ka, cb, ca)
+    dt = time.perf_counter() - t0
+    out["ckks"] = {"key_switches_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg4 key switch (N=2^15, 8+8 limbs)"}
+    # cfg5: gate bootstraps with the reference's own floating-point product (util/src/ring/fft/c64.rs restated)
+    n5, n_lwe5, lb5, d5 = 1024, 630, 7, 3
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2)  # noqa: E731
+    bra, brb, v = r64(n_lwe5, 2 * d5, n5), r64(n_lwe5, 2 * d5, n5), r64(n5)
+    ksa, ksb = r64(n5 * 5, n_lwe5), r64(n5 * 5)
+    threads = max(1, min(os.cpu_count() or 1, cref.num_threads(), 16))
+    a_raw, b_raw = r64(threads, n_lwe5), r64(threads)
+    cref.tfhe_bootstrap(lb5, d5, 4, 5, bra[:2], brb[:2], ksa[:, :2].copy(), ksb, v, a_raw[:1, :2].copy(), b_raw[:1], fft=True)  # twiddle set-up
+    t0 = time.perf_counter()
+    cref.tfhe_bootstrap(lb5, d5, 4, 5, bra, brb, ksa, ksb, v, a_raw[:1], b_raw[:1], threads=1, fft=True)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cref.tfhe_bootstrap(lb5, d5, 4, 5, bra, brb, ksa, ksb, v, a_raw, b_raw, threads=threads, fft=True)
+    dtm = time.perf_counter() - t0
+    out["tfhe"] = {"gate_bootstraps_per_sec": threads / dtm, "cores": threads, "kind": "port", "single_thread_value": 1.0 / dt1,
+                   "sample": "%d cfg5 gate bootstraps, one per thread, f64 FFT products as in the reference" % threads}
+    return out
 
 
-def load_pmc(key):
-    """A figure of the dominant kernel from the committed PMC summary (profiles/pmc_summary.json), if any."""
+def load_pmc():
+    """Counter figures of the dominant kernel from the committed PMC summary (profiles/pmc_summary.json), if any."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(p) as f:
-            return json.load(f).get(key)
+            return json.load(f)
     except Exception:
-        return None
+        return {}
 
 
-def load_traffic():
-    return load_pmc("ntt_fwd_bytes_per_launch")
+def sharded_secondary(torch, F, dist, dev, local_rank, rank, world, backend):
+    """SURVEY.md 8(e) rows 2 and 3 under the multi-GPU launch: cfg3 / cfg5 ciphertext batches split across the ranks (keys
+    replicated, no collective), cfg4 with the RNS limbs sharded (L = K = world: one all-gather of the p-limb products per key
+    switch, timed apart).  Rates are whole-job: units of all ranks / max time over ranks."""
+    from learn_fhe_amd.shard import shard_range, GpuLimbOps, ckks_key_switch_limb_sharded, dist_all_gather
+
+    def job_rate(units_total, fn, reps):
+        fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return units_total * reps / float(t.item())
+
+    out = {}
+    # cfg3: 1024 ciphertexts per GPU
+    S = fhew_setup(torch, F, dev, local_rank)
+    total = 1024 * world
+    lo, hi = shard_range(total, rank, world)
+    lwe_a = torch.randint(0, S["n"], (hi - lo, S["n_lwe"]), dtype=torch.int64, device=dev, generator=S["gen"]) * 2 + 1
+    lwe_b = torch.randint(0, 2 * S["n"], (hi - lo,), dtype=torch.int64, device=dev, generator=S["gen"])
+    out["fhew_blind_rotations_per_sec"] = job_rate(total, lambda: S["bk"].blind_rotate(lwe_a, lwe_b, S["f"]), 3)
+    # cfg5: BASELINE's 8192 ciphertexts over 8 GPUs = 1024 per GPU
+    T = tfhe_setup(torch, F, dev, local_rank, 1024)
+    out["tfhe_gate_bootstraps_per_sec"] = job_rate(1024 * world, lambda: T["key"].bootstrap(T["ks_lb"], T["ks_d"], T["ksa"], T["ksb"], T["v"], T["a_raw"], T["b_raw"]), 1)
+    # cfg4: limbs sharded, L = K = world
+    import ctypes as C
+    n = 1 << 15
+    primes = (C.c_uint64 * (2 * world))()
+    if F.lib().fhe_two_adic_primes(60, 16, 2 * world, primes) == 2 * world:
+        qs, ps = list(primes)[:world], list(primes)[world:]
+        ops = GpuLimbOps(F, qs, ps, rank, device=local_rank)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(40)  # the same ciphertext on every rank (ct.a is replicated at staging)
+        ct_a_all = torch.stack([torch.randint(0, m, (n,), dtype=torch.int64, device=dev, generator=gen) for m in qs])
+        ct_b = torch.randint(0, qs[rank], (n,), dtype=torch.int64, device=dev, generator=gen)
+        keys = [ops.key_to_eval(w_, torch.randint(0, m, (n,), dtype=torch.int64, device=dev, generator=gen), n)
+                for w_, m in (("q", qs[rank]), ("q", qs[rank]), ("p", ps[rank]), ("p", ps[rank]))]
+        gather_s = [0.0]
+
+        def timed_gather(x):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            y = dist_all_gather(x)
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - t0
+            return y
+
+        ks = lambda: ckks_key_switch_limb_sharded(ops, rank, world, n, ct_b, ct_a_all, keys[0], keys[1], keys[2], keys[3], timed_gather)  # noqa: E731
+        reps = 5
+        out["ckks_limb_sharded_key_switches_per_sec"] = job_rate(1, ks, reps)
+        out["ckks_all_gather_ms_per_key_switch"] = gather_s[0] / (reps + 1) * 1e3
+        out["ckks_limbs"] = "L = K = %d (one q-limb and one p-limb per rank), N = 2^15" % world
+    return out
 
 
-def issue_roofline(torch, dev, batch, fwd_ms):
-    """Secondary, for interpretation only (hard part 1): how close the forward kernel runs to the integer
-    ISSUE ceiling of its own instruction stream -- VALU instructions per wave (SQ_INSTS_VALU / SQ_WAVES from the committed
-    counter run) x 8 waves per polynomial, one wave-instruction per SIMD every ~4.3 cycles (4 for plain integer ops, ~4.7 for
-    v_mad_u64_u32: tools/microbench_intmul.hip), 4 SIMDs per CU at the device's maximum clock."""
-    insts = load_pmc("ntt_fwd_valu_insts_per_wave")
-    if not insts:
-        return None
-    prop = torch.cuda.get_device_properties(dev)
-    clock_hz = getattr(prop, "clock_rate", 2400000) * 1e3
-    simds = prop.multi_processor_count * 4
-    ceiling_ms = insts * 8 * batch * 4.3 / (simds * clock_hz) * 1e3
-    return {"valu_insts_per_wave": insts, "ceiling_ms_at_max_clock": ceiling_ms, "frac_of_issue_ceiling": ceiling_ms / fwd_ms,
-            "max_clock_mhz": clock_hz / 1e6, "simds": simds}
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare interpreter: start the N ranks ourselves (children are fresh processes; this
+    parent has not touched the GPU), relay their output and exit code."""
+    import torch  # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if not args.single_device and have < args.gpus:
+        print("bench.py: --gpus %d but only %d device(s) visible; refusing to report a %d-GPU number from fewer GPUs "
+              "(rehearse the control path with --dist-backend gloo --single-device)" % (args.gpus, have, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)  # ~0.15 s timed: the GPU needs ~10 ms of load to reach steady clocks
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=BATCH, help="polynomials per GPU (default: BASELINE cfg2)")
+    ap.add_argument("--preheat-ms", type=float, default=100.0,
+                    help="untimed run of the same kernels before the warm-up steps: the GPU needs ~10 ms of load to settle its clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the final all_gather of results (not in value)")
-    ap.add_argument("--no-fhew", action="store_true", help="skip the secondary figures (cfg3 FHEW, cfg4 CKKS, cfg5 TFHE)")
+    ap.add_argument("--no-fhew", action="store_true", help="skip the secondary figures (ring product, cfg3 FHEW, cfg4 CKKS, cfg5 TFHE)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the control path)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (only meaningful with --dist-backend gloo)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # does not return
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run `python bench.py --gpus N` without a launcher)"
+              % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
     import torch
     import learn_fhe_amd as F
     from learn_fhe_amd.shard import shard_range
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if args.single_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d has no device cuda:%d" % (rank, local_rank), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -235,9 +390,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+    n_gpus = world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -249,6 +402,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(2 + rank)
     a = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
+    a_init = a.clone()  # the run is forward+inverse pairs: at the end the buffer must equal this, bit for bit
 
     def barrier():
         torch.cuda.synchronize()
@@ -256,6 +410,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # time-based pre-heat (outside `warmup`, outside the timed region)
+    t0 = time.perf_counter()
+    preheat_steps = 0
+    while (time.perf_counter() - t0) * 1e3 < args.preheat_ms:
+        for _ in range(8):
+            ctx.ntt_(a, n)
+            ctx.intt_(a, n)
+        preheat_steps += 8
+        torch.cuda.synchronize()
+    preheat_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(args.warmup):
         ctx.ntt_(a, n)
         ctx.intt_(a, n)
@@ -278,6 +442,20 @@ def main():
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
+    # ---- verification of what was timed (outside the timed region) ----
+    import numpy as np
+    from oracle import cref  # the checker, never the thing measured
+    round_trip_ok = bool(torch.equal(a, a_init))
+    chk = a_init[:64].clone()
+    ctx.ntt_(chk, n)
+    fwd_ok = bool(np.array_equal(chk.cpu().numpy().view(np.uint64).reshape(-1),
+                                 cref.ntt_fwd(Q, a_init[:64].cpu().numpy().view(np.uint64).reshape(-1), n, threads=8)))
+    verified = round_trip_ok and fwd_ok
+    if dist is not None:
+        v = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(v.item() == 1.0)
+
     gather_ms = None
     if args.gather and dist is not None:
         from learn_fhe_amd.shard import gather_results
@@ -287,41 +465,63 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - t0) * 1e3
 
+    sharded = None
+    if dist is not None and not args.no_fhew:
+        sharded = sharded_secondary(torch, F, dist, dev, local_rank, rank, world, args.dist_backend)
+
     if rank == 0:
         transforms = 2.0 * total * args.steps
         achieved = ALGO_BYTES_PER_NTT * batch / (fwd_ms * 1e-3) / 1e9
+        pmc = load_pmc() if args.batch == BATCH else {}
         out = {
             "metric": "NTTs/sec at N=2^14 q~60-bit", "value": transforms / elapsed, "unit": "NTTs/sec",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "preheat_ms": preheat_ms,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "verified": verified,
+            "verification": {"round_trip_after_%d_fwd_inv_pairs_is_identity" % (preheat_steps + args.warmup + args.steps): round_trip_ok,
+                             "forward_of_64_polynomials_equals_cpu_oracle": fwd_ok},
             "config": {"workload": "cfg2: batched forward+inverse negacyclic NTT, N=2^14, q=%d, batch=%d per GPU, "
                                    "HBM-resident" % (Q, args.batch), "n": n, "q": Q, "batch_per_gpu": args.batch,
                        "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
-            "roofline": {"bound": "hbm", "kernel": "ntt14_fwd_kernel<ArithPM<60>> (forward transform)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": FWD_KERNEL, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic() if args.batch == BATCH else None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
+                         "traffic": pmc.get("ntt_fwd_bytes_per_launch"), "traffic_source": "profiles/pmc_summary.json (committed counter run of this "
+                         "kernel, FETCH_SIZE x2 + WRITE_SIZE; not re-measured by this process)" if pmc.get("ntt_fwd_bytes_per_launch") else None,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
+                         "inv_kernel": "ntt14w_inv_kernel<ArithPM<60>, false>",
                          "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9,
-                         "issue": issue_roofline(torch, dev, batch, fwd_ms)},
+                         "inv_frac": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "secondary_bound": "VALU issue (64-bit modular butterflies on 32-bit multipliers): see DESIGN.md 4.3; "
+                                            "valu_insts_per_wave from the committed counter run: %s" % pmc.get("ntt_fwd_valu_insts_per_wave")},
         }
         prop = torch.cuda.get_device_properties(dev)
         out["device"] = {"name": prop.name, "compute_units": prop.multi_processor_count, "max_clock_mhz": getattr(prop, "clock_rate", 2400000) / 1e3,  # torch builds without the field: the 2.4 GHz specification
                          "hbm_gib": round(prop.total_memory / 2 ** 30, 1), "hbm_peak_gbs_used": HBM_PEAK_GBS}
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if sharded is not None:
+            out["sharded"] = sharded
         if n_gpus == 1 and not args.no_fhew:
+            out["ntt_mul"] = ntt_mul_bench(torch, F, dev, local_rank, min(args.batch, 2048))
             out["fhew"] = fhew_bench(torch, F, dev, local_rank)
             out["ckks"] = ckks_bench(torch, F, dev, local_rank)
             out["tfhe"] = tfhe_bench(torch, F, dev, local_rank)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if not args.no_fhew:
-                out["cpu_baseline"]["fhew"] = cpu_fhew_baseline()
+                sec = cpu_secondary_baselines()
+                out["cpu_baseline"]["fhew"] = sec["fhew"]
+                out["cpu_baseline"]["ckks"] = sec["ckks"]
+                out["cpu_baseline"]["tfhe"] = sec["tfhe"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not verified:
+        print("bench.py: VERIFICATION FAILED (see `verification` in the JSON line)", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -231,6 +231,13 @@ int fhe_tglwe_sample_extract(const uint64_t *ct_a, const uint64_t *ct_b, size_t 
 /* scheme/tfhe/src/tlwe.rs:144-153 `Tlwe::key_switch`: ksk_a [n_in*d][n_out], ksk_b [n_in*d], rows digit-major. */
 int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a, const uint64_t *ct_b,
                         size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/bootstrapping.rs:78-82 `Bootstrapping::bootstrap(bsk, v, ct)` for `batch` TLWE ciphertexts in one call:
+ * mod switch (99-104) -> blind rotation (84-96) -> sample_extract(0) -> key switch, on `stream`.  lwe_a [batch][n_lwe], lwe_b
+ * [batch] (n_lwe = number of TGGSW ciphertexts in brk), v [n] the encoded test polynomial, ksk as in fhe_tlwe_key_switch with
+ * n_in = n, n_out = n_lwe; out_a [batch][n_lwe], out_b [batch].  Bit-identical to the four calls above chained. */
+int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_log_b, int ks_d, const uint64_t *ksk_a,
+                       const uint64_t *ksk_b, const uint64_t *v, const uint64_t *lwe_a, const uint64_t *lwe_b, uint64_t *out_a,
+                       uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
 
 #ifdef __cplusplus
 }

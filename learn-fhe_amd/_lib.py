@@ -119,6 +119,7 @@ def lib():
         L.fhe_tfhe_blind_rotate.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
+        L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib
 

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__rest
     w14::fwd_one<A>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
 }
 
-template <class A, bool PFX>
+// MUL: the launch carries a pointwise multiplier (io.mul), a separate instantiation so that plain transforms do not carry its code
+template <class A, bool PFX, bool MUL = false>
 __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
                                                                        unsigned subs, int pb, NttIo io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__rest
     w14::tw7_load<A, true, 1>(d[1], (w << 8) | lane, k);
     const int off = (w << 11) | (lane << 3);
     const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << 14) : g) + off;
-    if (io.mul) {  // workgroup-uniform
+    if constexpr (MUL) {
         const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << 14) + off;
         w14::load_mul_p3<A, 0>(x, src, mul, k); w14::load_mul_p3<A, 1>(x, src, mul, k);
         w14::load_mul_p3<A, 2>(x, src, mul, k); w14::load_mul_p3<A, 3>(x, src, mul, k);

@@ -89,8 +89,8 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // 16-byte form makes that wait longer than the instructions it saves).
 template <class AF, class AI>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
-    auto k = pb ? (inv ? fhe::ntt14w_inv_kernel<AI, true> : fhe::ntt14w_fwd_kernel<AF, true>)
-                : (inv ? fhe::ntt14w_inv_kernel<AI, false> : fhe::ntt14w_fwd_kernel<AF, false>);
+    auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true> : fhe::ntt14w_inv_kernel<AI, true, false>) : fhe::ntt14w_fwd_kernel<AF, true>)
+                : (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, false, true> : fhe::ntt14w_inv_kernel<AI, false, false>) : fhe::ntt14w_fwd_kernel<AF, false>);
     HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::LDS_BYTES));
     hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::THREADS), fhe::w14::LDS_BYTES, st, a, d, nd, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());

@@ -470,4 +470,39 @@ int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t 
     return rc != FHE_OK ? rc : mob.sync_out(st);
 }
 
+// scheme/tfhe/src/bootstrapping.rs:78-82 `Bootstrapping::bootstrap` for `batch` TLWE ciphertexts in ONE call: mod switch (99-104),
+// blind rotation (84-96), sample_extract(0) (tglwe.rs:115-127), TLWE key switch (tlwe.rs:144-153), all on `stream`, intermediates
+// in stream-ordered scratch.  Bit-identical to the four separate calls.
+int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_log_b, int ks_d, const uint64_t *ksk_a, const uint64_t *ksk_b,
+                       const uint64_t *v, const uint64_t *lwe_a, const uint64_t *lwe_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
+                       void *stream) {
+    fhe::TDecomp P;
+    int rc = make_tdecomp(ks_log_b, ks_d, &P);
+    if (rc != FHE_OK) return rc;
+    if (!t || !brk || brk->t != t || !ksk_a || !ksk_b || !v || ((!lwe_a || !lwe_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << brk->log_n, n_lwe = brk->count, rows = n * ks_d;
+    Mirror mka(ksk_a, rows * n_lwe, mem, true, st), mkb(ksk_b, rows, mem, true, st), mv(v, n, mem, true, st),
+        ma(lwe_a, n_lwe * batch, mem, true, st), mb(lwe_b, batch, mem, true, st), moa(out_a, n_lwe * batch, mem, false, st),
+        mob(out_b, batch, mem, false, st);
+    if (mka.rc | mkb.rc | mv.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    StreamWs ws((batch * n_lwe + batch + 3 * batch * n + batch) * sizeof(u64), st);  // a~ | b~ | acc.a | acc.b | extracted a | b
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *at = ws.as<u64>(), *bt = at + batch * n_lwe, *ra = bt + batch, *rb = ra + batch * n, *ea = rb + batch * n, *eb = ea + batch * n;
+    typedef uint64_t U;
+    rc = fhe_tfhe_mod_switch((const U *)ma.d, (U *)at, batch * n_lwe, n, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_tfhe_mod_switch((const U *)mb.d, (U *)bt, batch, n, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_tfhe_blind_rotate(t, brk, (const U *)at, (const U *)bt, (const U *)mv.d, (U *)ra, (U *)rb, batch, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = fhe_tglwe_sample_extract((const U *)ra, (const U *)rb, n, 0, (U *)ea, (U *)eb, batch, FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK)
+        rc = fhe_tlwe_key_switch(ks_log_b, ks_d, (const U *)mka.d, (const U *)mkb.d, (const U *)ea, (const U *)eb, n, n_lwe, (U *)moa.d, (U *)mob.d, batch,
+                                 FHE_MEM_DEVICE, stream);
+    if (rc == FHE_OK) rc = moa.sync_out(st);
+    if (rc == FHE_OK) rc = mob.sync_out(st);
+    return rc;
+}
+
 }  // extern "C"

@@ -479,6 +479,20 @@ class TggswKey:
         L.check(L.lib().fhe_tfhe_blind_rotate(self.t.handle, self._h, pa, pb, pv, poa, pob, batch, mem, st), "fhe_tfhe_blind_rotate")
         return out_a, out_b
 
+    def bootstrap(self, ks_log_b, ks_d, ksk_a, ksk_b, v, lwe_a, lwe_b):
+        """scheme/tfhe/src/bootstrapping.rs:78-82 in one call: lwe_a [batch][n_lwe], lwe_b [batch] -> (a [batch][n_lwe], b [batch])."""
+        pka, _, mem, st = _buf(ksk_a)
+        pkb, _, _, _ = _buf(ksk_b)
+        pv, _, _, _ = _buf(v)
+        pa, _, _, _ = _buf(lwe_a)
+        pb, batch, _, _ = _buf(lwe_b)
+        out_a, out_b = _like(lwe_a, (batch, self.count)), _like(lwe_a, (batch,))
+        poa, _, _, _ = _buf(out_a)
+        pob, _, _, _ = _buf(out_b)
+        L.check(L.lib().fhe_tfhe_bootstrap(self.t.handle, self._h, ks_log_b, ks_d, pka, pkb, pv, pa, pb, poa, pob, batch, mem, st),
+                "fhe_tfhe_bootstrap")
+        return out_a, out_b
+
 
 def tglwe_sample_extract(ct_a, ct_b, n, index):
     pa, cnt, mem, st = _buf(ct_a)

@@ -237,3 +237,20 @@ def test_c_program_through_the_abi(tmp_path, fhe):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "c_abi_demo ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_c_program_sharding_over_devices(tmp_path, fhe):
+    """examples/multi_gpu_demo.c: SURVEY.md 8(e) at the C boundary -- one process, one context + stream + shard per device (two
+    shards on two streams of the device on a one-GPU box), asynchronous entry points, the caller's own gather; sharded result
+    bit-equal to the single-device result"""
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.dirname(fhe.lib_path())
+    exe = tmp_path / "multi_gpu_demo"
+    cmd = ["gcc", "-std=c99", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "multi_gpu_demo.c"), "-o", str(exe), "-L", lib_dir, "-lfhe_ring", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "multi_gpu_demo ok" in r.stdout, r.stdout + r.stderr

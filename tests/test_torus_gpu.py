@@ -303,6 +303,12 @@ def test_blind_rotate_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, n_lwe, ba
     ksa, ksb = r64(n * ks_d, n_lwe), r64(n * ks_d)
     ea, eb = fhe.tglwe_sample_extract(oa, ob, n, 0)
     ka, kb = fhe.tlwe_key_switch(ks_log_b, ks_d, dev(torch_cuda, ksa), dev(torch_cuda, ksb), ea, eb, n, n_lwe)
+    # the single-call gate (bootstrapping.rs:78-82, fhe_tfhe_bootstrap) is the same four steps on one stream: bit-identical
+    ga1, gb1 = key.bootstrap(ks_log_b, ks_d, dev(torch_cuda, ksa), dev(torch_cuda, ksb), dev(torch_cuda, v), dev(torch_cuda, a_raw), dev(torch_cuda, b_raw))
+    assert torch_cuda.equal(ga1, ka) and torch_cuda.equal(gb1, kb)
+    if batch <= 16:  # ... and with every operand in host memory
+        ga2, gb2 = key.bootstrap(ks_log_b, ks_d, ksa, ksb, v, a_raw, b_raw)
+        assert np.array_equal(ga2, host(ka).reshape(batch, n_lwe)) and np.array_equal(gb2, host(kb))
     pick = list(range(batch)) if batch <= 16 else sorted(set([0, 1, 63, 64, 255, 256, 511, 512, 513, batch - 2, batch - 1] + list(range(7, batch, 97))))
     ga, gb = cref.tfhe_bootstrap(log_b, d, ks_log_b, ks_d, bra, brb, ksa, ksb, v, a_raw[pick], b_raw[pick], threads=16)
     ra_, rb_ = cref.tfhe_blind_rotate(log_b, d, bra, brb, v, cref.tfhe_mod_switch(a_raw[pick], n), cref.tfhe_mod_switch(b_raw[pick], n), threads=16)
