@@ -26,10 +26,32 @@ struct DSNone : ArithDS<60> {  // ablation: HBM traffic + exchanges only
     template <int PH = 1> static __device__ __forceinline__ void gs_last_scaled(u64 &X, u64 &Y, const K &) { X ^= 1; Y ^= 1; }
 };
 
+// counter calibration: plain coalesced copies of a known byte count, 8 and 16 bytes per lane (the transforms' access widths)
+__global__ void copy8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) out[i] = in[i] + 1;
+}
+__global__ void copy16_kernel(const ulonglong2 *__restrict__ in, ulonglong2 *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        ulonglong2 v = in[i]; v.x += 1; out[i] = v;
+    }
+}
 static int g_pgrid = 512;
 #define GRID(v) (batch)
 int main(int argc, char **argv) {
     if (argc > 3) g_pgrid = atoi(argv[3]);
+    if (argc > 1 && argv[1][0] == 'c') {  // ./lab2 calib : 512 MiB in, 512 MiB out, both widths
+        size_t n = size_t(64) << 20;
+        u64 *a, *b;
+        hipMalloc(&a, n * 8); hipMalloc(&b, n * 8);
+        hipMemset(a, 1, n * 8);
+        for (int r = 0; r < 3; ++r) {
+            copy8_kernel<<<4096, 256>>>(a, b, n);
+            copy16_kernel<<<4096, 256>>>((const ulonglong2 *)a, (ulonglong2 *)b, n / 2);
+        }
+        hipDeviceSynchronize();
+        printf("calib: copy8_kernel and copy16_kernel each read %zu and write %zu bytes per launch\n", n * 8, n * 8);
+        return 0;
+    }
     const u64 q = 1152921504606748673ull;
     const int n = 1 << 14, batch = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 20;
     const int s = __builtin_ctzll(q - 1);

@@ -71,13 +71,45 @@ def find_avg(kern, counter):
     return None
 
 
-fw_r, fw_w = find(("ntt14_fwd_kernel<", "ArithPM<60>"), "FETCH_SIZE"), find(("ntt14_fwd_kernel<", "ArithPM<60>"), "WRITE_SIZE")
+FWD = ("prof_pmc", "ntt14w_fwd_kernel<", "ArithDS<60>, false")
+fw_r, fw_w = find(FWD, "FETCH_SIZE"), find(FWD, "WRITE_SIZE")
 if fw_r and fw_w:
-    insts, waves = find_avg(("ntt14_fwd_kernel<", "ArithPM<60>, false"), "SQ_INSTS_VALU"), find_avg(("ntt14_fwd_kernel<", "ArithPM<60>, false"), "SQ_WAVES")
-    json.dump({"source": "profiles/%s_pmc.json" % tag, "kernel": "ntt14_fwd_kernel<ArithPM<60>> (forward, batch 4096)",
+    insts, waves = find_avg(FWD, "SQ_INSTS_VALU"), find_avg(FWD, "SQ_WAVES")
+    cyc, wait, stall, act = (find_avg(FWD, c) for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"))
+    calib = {k: e for k, e in summary.items() if "prof_calib" in k}
+    json.dump({"source": "profiles/%s_pmc.json" % tag, "kernel": "ntt14w_fwd_kernel<ArithDS<60>, false> (forward, batch 4096)",
                "ntt_fwd_read_bytes_per_launch": fw_r, "ntt_fwd_write_bytes_per_launch": fw_w,
                "ntt_fwd_bytes_per_launch": fw_r + fw_w,
                "ntt_fwd_valu_insts_per_wave": (insts / waves) if insts and waves else None,
+               "ntt_fwd_wave_cycle_split": {"parked (s_waitcnt / barrier)": wait / cyc, "issue stalled": stall / cyc, "issuing": act / cyc} if cyc and wait and stall and act else None,
+               "calibration": {k.split(":")[1]: {c: v for c, v in e.items() if c.endswith("_corrected_bytes")} for k, e in calib.items()},
                "correction": "FETCH_SIZE x2 (gfx950 reads 1/2, calibrated on copy8/copy16 of 512 MiB), WRITE_SIZE x1, KiB"},
               open(os.path.join("profiles", "pmc_summary.json"), "w"), indent=1)
     print("wrote profiles/pmc_summary.json", fw_r + fw_w)
+
+# per-kernel counters of the secondary workloads (bench.py blocks ntt_mul / fhew / ckks / tfhe): HBM bytes per launch and the
+# wave-cycle split, for the kernels that dominate them
+SECONDARY = ("blind_rotate_kernel", "torus30_blind_rotate_kernel", "external_product_kernel", "ntt14w_fwd_kernel", "ntt14w_inv_kernel", "ntt_big_fwd_pass",
+             "ntt_big_inv_pass", "rns_rescale_kernel", "rns_extend_kernel", "tlwe_key_switch", "lwe_key_switch")
+sec = {}
+for k, e in summary.items():
+    if not k.startswith("prof_sec"):
+        continue
+    name = k.split(":", 1)[1]
+    if not any(n in name for n in SECONDARY):
+        continue
+    d = sec.setdefault(name, {})
+    for c, v in e.items():
+        if c.endswith("_corrected_bytes") or c.endswith("_avg"):
+            d[c] = v
+for name, d in sec.items():
+    if "SQ_WAVE_CYCLES_avg" in d and d["SQ_WAVE_CYCLES_avg"]:
+        d["wave_cycle_split"] = {"parked": d.get("SQ_WAIT_ANY_avg", 0) / d["SQ_WAVE_CYCLES_avg"], "issue_stalled": d.get("SQ_WAIT_INST_ANY_avg", 0) / d["SQ_WAVE_CYCLES_avg"],
+                                 "issuing": d.get("SQ_ACTIVE_INST_ANY_avg", 0) / d["SQ_WAVE_CYCLES_avg"]}
+    if "SQ_INSTS_VALU_avg" in d and d.get("SQ_WAVES_avg"):
+        d["valu_insts_per_wave"] = d["SQ_INSTS_VALU_avg"] / d["SQ_WAVES_avg"]
+    if "FETCH_SIZE_corrected_bytes" in d and "WRITE_SIZE_corrected_bytes" in d:
+        d["hbm_bytes_per_launch"] = d["FETCH_SIZE_corrected_bytes"] + d["WRITE_SIZE_corrected_bytes"]
+if sec:
+    json.dump(sec, open(os.path.join("profiles", tag + "_secondary_pmc.json"), "w"), indent=1)
+    print("wrote profiles/%s_secondary_pmc.json (%d kernels)" % (tag, len(sec)))
