@@ -45,6 +45,14 @@ typedef struct fhe_ctx fhe_ctx; /* one prime modulus: s, g, omega, twiddle table
 
 const char *fhe_version(void);
 int fhe_last_hip_error(void);
+/* Device scratch of the entry points comes from a private stream-ordered pool per device (never the device's default pool);
+ * freed blocks are kept for the next call up to 4 GiB.  fhe_trim() returns everything that is not in use to the driver. */
+int fhe_trim(void);
+
+/* Entry points that take a modulus instead of a context (fhe_rq_*, fhe_decompose, fhe_automorphism, fhe_monomial_mul,
+ * fhe_lwe_*, fhe_rlwe_sample_extract, fhe_torus_decompose, fhe_tfhe_mod_switch, fhe_tglwe_sample_extract, fhe_tlwe_key_switch)
+ * run on the device their FHE_MEM_DEVICE operands live on, whatever the caller's current device is; `stream` must belong to
+ * that device.  With FHE_MEM_HOST they run on the current device. */
 
 /* ---- scalar / setup (host only) -------------------------------------------------------------- */
 /* util/src/zq.rs:337-342 `is_prime` */
@@ -137,7 +145,11 @@ void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk);
  * lwe_a [batch][n_lwe] and lwe_b [batch] are taken mod 2n (after mod_switch_odd); f = LUT polynomial(s),
  * f_stride = 0 (one f) or n (one per ciphertext); out_a/out_b [batch][n] = the rotated accumulator.
  * ops_out/nops_out (host pointers, may be NULL): the walk of blind_rotate_core per ciphertext,
- * [batch][n_lwe + n + 2] entries, bit 31 set = automorphism ak[idx], clear = external product brk[idx]. */
+ * [batch][n_lwe + n + 2] entries, bit 31 set = automorphism ak[idx], clear = external product brk[idx].
+ * lwe_b is reduced mod 2n; every lwe_a entry must already be an ODD residue below 2n (what `mod_switch_odd`, lwe.rs:94-99,
+ * produces): anything else makes the reference index out of its log map and panic (bootstrapping.rs:221), here FHE_ERR_INVALID.
+ * That check is data dependent, so this entry point (and fhe_fhew_bootstrap, which ends with it) SYNCHRONISES `stream` before
+ * it returns, device-memory calls included -- the one exception to "device-memory calls are asynchronous". */
 int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const uint64_t *lwe_b, const uint64_t *f,
                      size_t f_stride, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream,
                      uint32_t *ops_out, uint32_t *nops_out);

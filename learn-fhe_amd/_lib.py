@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "lib", "libfhe_ring.so")
+# FHE_RING_LIB: developer override (tools/scripts/occ_sweep.sh: a build variant of the same library), never a fallback
+_SO = os.environ.get("FHE_RING_LIB") or os.path.join(_HERE, "lib", "libfhe_ring.so")
 _lib = None
 
 STATUS = {0: "FHE_OK", 1: "FHE_ERR_INVALID", 2: "FHE_ERR_NOT_PRIME", 3: "FHE_ERR_NO_ROOT", 4: "FHE_ERR_MODULUS",
@@ -119,6 +120,7 @@ def lib():
         L.fhe_tfhe_blind_rotate.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
+        L.fhe_trim.argtypes = []
         L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 
 #include "../../include/fhe_ring.h"
 #include "dev_arith.hpp"
@@ -42,25 +43,63 @@ struct DeviceGuard {
     }
 };
 
-// Per-call device workspace, allocated and released IN STREAM ORDER (hipMallocAsync / hipFreeAsync on the device's default
-// pool, whose release threshold is raised once so freed blocks are kept for the next call): an entry point neither pays a
-// device-wide hipMalloc / hipFree nor has to synchronise the stream before it returns to keep its workspace alive.
+// Entry points that take a modulus instead of a context have no device of their own: they run where their DEVICE operands
+// live (hipPointerGetAttributes of the first one), whatever the caller's current device is; host-memory calls use the current
+// device.
+struct PtrDeviceGuard {
+    DeviceGuard *g = nullptr;
+    bool ok = true;
+    PtrDeviceGuard(const void *p, fhe_mem mem) {
+        if (mem != FHE_MEM_DEVICE || !p) return;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return; }  // not a HIP allocation: leave the device alone
+        g = new DeviceGuard(at.device);
+        ok = g->ok;
+    }
+    ~PtrDeviceGuard() { delete g; }
+    PtrDeviceGuard(const PtrDeviceGuard &) = delete;
+    PtrDeviceGuard &operator=(const PtrDeviceGuard &) = delete;
+};
+}  // namespace
+
+// Per-call device workspace, allocated and released IN STREAM ORDER from a pool of the LIBRARY'S OWN (one per device, created on
+// first use): an entry point neither pays a device-wide hipMalloc / hipFree nor has to synchronise the stream before it returns
+// to keep its workspace alive, and the device's default pool -- which a co-resident framework may be using -- keeps its
+// settings.  The pool holds on to freed blocks up to FHE_POOL_KEEP_BYTES; fhe_trim() hands everything back to the driver.
+namespace fhe {
+constexpr uint64_t POOL_KEEP_BYTES = uint64_t(4) << 30;
+constexpr int MAX_DEVICES = 64;
+inline hipMemPool_t g_pools[MAX_DEVICES] = {};
+inline hipMemPool_t private_pool(int dev) {
+    static std::mutex mu;
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!g_pools[dev]) {
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) != hipSuccess) return nullptr;
+        uint64_t keep = POOL_KEEP_BYTES;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        g_pools[dev] = pool;
+    }
+    return g_pools[dev];
+}
+}  // namespace fhe
+
+namespace {
 struct StreamWs {
     void *p = nullptr;
     hipStream_t st;
     int rc = FHE_OK;
     StreamWs(size_t bytes, hipStream_t s) : st(s) {
-        static thread_local int pool_ready_for = -1;
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && pool_ready_for != dev) {
-            hipMemPool_t pool;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                uint64_t keep = ~uint64_t(0);
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            pool_ready_for = dev;
-        }
-        const hipError_t e = hipMallocAsync(&p, bytes ? bytes : 8, s);
+        hipError_t e = hipGetDevice(&dev);
+        hipMemPool_t pool = e == hipSuccess ? fhe::private_pool(dev) : nullptr;
+        if (e == hipSuccess) e = pool ? hipMallocFromPoolAsync(&p, bytes ? bytes : 8, pool, s) : hipMallocAsync(&p, bytes ? bytes : 8, s);
         if (e != hipSuccess) { fhe::g_last_hip = (int)e; rc = FHE_ERR_HIP; p = nullptr; }
     }
     ~StreamWs() {
@@ -80,12 +119,16 @@ struct Mirror {
     size_t bytes = 0;
     bool owned = false;
     int rc = FHE_OK;
-    Mirror(const void *p, size_t count, fhe_mem mem, bool copy_in, hipStream_t st) {
+    hipStream_t st_ = nullptr;
+    Mirror(const void *p, size_t count, fhe_mem mem, bool copy_in, hipStream_t st) : st_(st) {
         bytes = count * sizeof(u64);
         if (mem == FHE_MEM_DEVICE || count == 0) { d = (u64 *)p; return; }
         host = const_cast<void *>(p);
         owned = true;
-        hipError_t e = hipMalloc((void **)&d, bytes);
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        hipMemPool_t pool = e == hipSuccess ? fhe::private_pool(dev) : nullptr;
+        if (e == hipSuccess) e = pool ? hipMallocFromPoolAsync((void **)&d, bytes, pool, st) : hipMallocAsync((void **)&d, bytes, st);
         if (e == hipSuccess && copy_in) e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { fhe::g_last_hip = (int)e; rc = FHE_ERR_HIP; }
     }
@@ -97,7 +140,7 @@ struct Mirror {
         return rc;
     }
     ~Mirror() {
-        if (owned && d) (void)hipFree(d);
+        if (owned && d) (void)hipFreeAsync(d, st_);  // stream ordered: after the kernels and copies that use it
     }
     Mirror(const Mirror &) = delete;
     Mirror &operator=(const Mirror &) = delete;

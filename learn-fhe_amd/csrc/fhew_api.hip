@@ -165,6 +165,8 @@ extern "C" {
 
 int fhe_decompose(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem,
                   void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     fhe::DecompParams P;
     int rc = make_decomp(q, log_b, d, &P);
     if (rc != FHE_OK) return rc;
@@ -180,6 +182,8 @@ int fhe_decompose(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, si
 
 int fhe_automorphism(uint64_t q, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
                      void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || !is_pow2(n) || n > (1u << 30) || ((!in || !out) && batch) || in == out) return FHE_ERR_INVALID;
     if (batch == 0) return FHE_OK;
     const int64_t two_n = 2 * (int64_t)n;
@@ -196,6 +200,8 @@ int fhe_automorphism(uint64_t q, int64_t t, const uint64_t *in, uint64_t *out, s
 
 int fhe_monomial_mul(uint64_t q, int64_t k, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
                      void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || !is_pow2(n) || n > (1u << 30) || ((!in || !out) && batch) || in == out) return FHE_ERR_INVALID;
     if (batch == 0) return FHE_OK;
     const int64_t two_n = 2 * (int64_t)n;
@@ -311,6 +317,8 @@ int fhe_rlwe_automorphism(const fhe_ctx *ctx, const fhe_key *ak, size_t index, i
 
 // util/src/zq.rs:128-140 via scheme/fhew/src/lwe.rs:90-99: v -> round(v * q_prime / q) (odd != 0: `mod_switch_odd`)
 int fhe_lwe_mod_switch(uint64_t q, uint64_t q_prime, const uint64_t *in, uint64_t *out, size_t count, int odd, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || q_prime < 2 || ((!in || !out) && count)) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -325,6 +333,8 @@ int fhe_lwe_mod_switch(uint64_t q, uint64_t q_prime, const uint64_t *in, uint64_
 int fhe_lwe_key_switch(uint64_t q, int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a,
                        const uint64_t *ct_b, size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
                        void *stream) {
+    PtrDeviceGuard pguard(ct_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     fhe::DecompParams P;
     int rc = make_decomp(q, log_b, d, &P);
     if (rc != FHE_OK) return rc;
@@ -354,6 +364,8 @@ int fhe_lwe_key_switch(uint64_t q, int log_b, int d, const uint64_t *ksk_a, cons
 // scheme/fhew/src/lwe.rs:22-75: out = sum_k coef[k] * in[k] + addend over q (the gates' linear parts, fhew.rs:27-29, 61-69)
 int fhe_lwe_lincomb(uint64_t q, int k, const int64_t *coef, const uint64_t *const *in, uint64_t addend, uint64_t *out, size_t count,
                     fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || (q >> 62) || k < 1 || k > 4 || !coef || !in || addend >= q || (!out && count)) return FHE_ERR_INVALID;
     for (int t = 0; t < k; ++t)
         if (!in[t] && count) return FHE_ERR_INVALID;
@@ -375,6 +387,8 @@ int fhe_lwe_lincomb(uint64_t q, int k, const int64_t *coef, const uint64_t *cons
 // scheme/fhew/src/rlwe.rs:193-202 `Rlwe::sample_extract(ct, index)`, b += addend (mod q)
 int fhe_rlwe_sample_extract(uint64_t q, const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t addend,
                             uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(ct_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || (q >> 62) || addend >= q || !is_pow2(n) || index >= n || n > (1u << 30) || ((!ct_a || !ct_b || !out_a || !out_b) && batch))
         return FHE_ERR_INVALID;
     if (batch == 0) return FHE_OK;
@@ -538,6 +552,11 @@ int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b,
                        const uint64_t *lwe_ksk_b, const uint64_t *f, size_t f_stride, uint64_t addend, const uint64_t *ct_a,
                        const uint64_t *ct_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
     if (!bk || !lwe_ksk_a || !lwe_ksk_b || !f || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    {   // the key-switch gadget sizes every buffer below: validate it before anything is allocated
+        fhe::DecompParams ksP;
+        const int vrc = make_decomp(q_ks, ks_log_b, ks_d, &ksP);
+        if (vrc != FHE_OK) return vrc;
+    }
     if (batch == 0) return FHE_OK;
     const fhe_ctx *ctx = bk->ctx;
     const size_t n = size_t(1) << bk->brk->log_n, n_lwe = bk->brk->count;

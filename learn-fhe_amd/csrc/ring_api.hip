@@ -213,6 +213,14 @@ extern "C" {
 const char *fhe_version(void) { return "learn-fhe_amd 0.1 (gfx950)"; }
 int fhe_last_hip_error(void) { return g_last_hip; }
 
+// hand the library's cached stream-ordered scratch (api_common.hpp: one private pool per device) back to the driver
+int fhe_trim(void) {
+    int rc = FHE_OK;
+    for (int dev = 0; dev < fhe::MAX_DEVICES; ++dev)
+        if (fhe::g_pools[dev] && hipMemPoolTrimTo(fhe::g_pools[dev], 0) != hipSuccess) rc = FHE_ERR_HIP;
+    return rc;
+}
+
 int fhe_is_prime(uint64_t q) { return fhe::is_prime_u64(q) ? 1 : 0; }
 
 int fhe_two_adic_primes(int bits, int log_n, int count, uint64_t *out) {
@@ -378,6 +386,8 @@ int fhe_pointwise_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t
 
 namespace {
 int rq_elementwise(uint64_t q, const void *a, const void *b, uint64_t *out, size_t len, int op, uint64_t scalar, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (q < 2 || (q >> 62) || ((!a || !out || (op < 2 && !b)) && len) || (op == 3 && scalar >= q)) return FHE_ERR_INVALID;
     if (len == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -217,6 +217,8 @@ int fhe_torus_ctx_create(int device, fhe_torus_ctx **out) {
 }
 
 int fhe_torus_decompose(int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     fhe::TDecomp P;
     int rc = make_tdecomp(log_b, d, &P);
     if (rc != FHE_OK) return rc;
@@ -363,6 +365,8 @@ int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key,
 
 // scheme/tfhe/src/bootstrapping.rs:99-104 `mod_switch`: v -> rounding_shr(v, 64 - log2(2 big_n)) for `count` torus values
 int fhe_tfhe_mod_switch(const uint64_t *in, uint64_t *out, size_t count, size_t big_n, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (!is_pow2(big_n) || ((!in || !out) && count)) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     const int bits = 64 - (ilog2(big_n) + 1);
@@ -422,6 +426,8 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
 // scheme/tfhe/src/tglwe.rs:115-127 `sample_extract(ct, i)` (k = 1): ct_a, ct_b [batch][n] -> TLWE (out_a [batch][n], out_b [batch])
 int fhe_tglwe_sample_extract(const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t index, uint64_t *out_a, uint64_t *out_b,
                              size_t batch, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(ct_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     if (!is_pow2(n) || index >= n || n > (1u << 30) || ((!ct_a || !ct_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
     if (batch == 0) return FHE_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -439,6 +445,8 @@ int fhe_tglwe_sample_extract(const uint64_t *ct_a, const uint64_t *ct_b, size_t 
 // input coefficient i); ct_a [batch][n_in], ct_b [batch] -> out_a [batch][n_out], out_b [batch]
 int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t *ksk_b, const uint64_t *ct_a, const uint64_t *ct_b,
                         size_t n_in, size_t n_out, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    PtrDeviceGuard pguard(ct_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
     fhe::TDecomp P;
     int rc = make_tdecomp(log_b, d, &P);
     if (rc != FHE_OK) return rc;

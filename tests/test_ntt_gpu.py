@@ -254,3 +254,23 @@ def test_c_program_sharding_over_devices(tmp_path, fhe):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "multi_gpu_demo ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_scratch_pool_is_private_and_trimmable(fhe, torch_cuda):
+    """device scratch comes from the library's own stream-ordered pool (api_common.hpp), not the device's default pool: a
+    host-memory call and a workspace-using device call leave the default pool's release threshold alone; fhe_trim() succeeds"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    pool, thr = C.c_void_p(), C.c_uint64(0)
+    assert hip.hipDeviceGetDefaultMemPool(C.byref(pool), 0) == 0
+    HIP_MEMPOOL_ATTR_RELEASE_THRESHOLD = 4  # hipMemPoolAttrReleaseThreshold
+    assert hip.hipMemPoolGetAttribute(pool, HIP_MEMPOOL_ATTR_RELEASE_THRESHOLD, C.byref(thr)) == 0
+    before = thr.value
+    q, n = 1073707009, 1024
+    ctx = fhe.NttContext(q)
+    a, b = rand_u64(5, q, 3 * n), rand_u64(6, q, 3 * n)
+    ctx.mul_(a.copy(), b, n)                       # host operands: mirrors + workspace
+    ctx.mul_(to_dev(torch_cuda, a), to_dev(torch_cuda, b), n)
+    torch_cuda.cuda.synchronize()
+    assert hip.hipMemPoolGetAttribute(pool, HIP_MEMPOOL_ATTR_RELEASE_THRESHOLD, C.byref(thr)) == 0 and thr.value == before
+    assert fhe.lib().fhe_trim() == 0

@@ -119,3 +119,68 @@ def test_two_rank_gloo_limb_sharded_ckks_key_switch(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+BOOTSTRAP_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from oracle import cref
+    from learn_fhe_amd.shard import shard_range, gather_results
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.Generator(np.random.PCG64(11))          # same seed on every rank: keys are REPLICATED, the batch is split
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+    # cfg5 shape at toy size: TFHE gate bootstraps (mod switch, CMUX chain, sample extract, key switch), 7 ciphertexts over 2 ranks
+    n, n_lwe, log_b, d, total = 32, 5, 10, 2, 7
+    bra, brb, v = r64(n_lwe, 2 * d, n), r64(n_lwe, 2 * d, n), r64(n)
+    ksa, ksb = r64(n * 5, n_lwe), r64(n * 5)
+    a_raw, b_raw = r64(total, n_lwe), r64(total)
+    lo, hi = shard_range(total, rank, world)
+    ga, gb = cref.tfhe_bootstrap(log_b, d, 4, 5, bra, brb, ksa, ksb, v, a_raw[lo:hi], b_raw[lo:hi])
+    width = -(-total // world)
+    pad = np.zeros((width, n_lwe + 1), dtype=np.uint64); pad[: hi - lo, :n_lwe] = ga; pad[: hi - lo, n_lwe] = gb
+    out = gather_results(T(pad)).numpy().view(np.uint64)   # the ONLY collective: the final gather of the output LWE ciphertexts
+    rows = [out[r * width: r * width + (shard_range(total, r, world)[1] - shard_range(total, r, world)[0])] for r in range(world)]
+    got = np.concatenate(rows, axis=0)
+    ea, eb = cref.tfhe_bootstrap(log_b, d, 4, 5, bra, brb, ksa, ksb, v, a_raw, b_raw)
+    assert np.array_equal(got[:, :n_lwe], ea) and np.array_equal(got[:, n_lwe], eb), "sharded TFHE gates != single-process result"
+    # cfg3 shape at toy size: LMKCDEY blind rotations, 5 ciphertexts over 2 ranks
+    q, n3, w, lb3, d3, nl3 = 1073707009, 16, 2, 6, 5, 4
+    assert cref.is_prime(q)
+    brk = rng.integers(0, q, size=(nl3, 2, 2 * d3, n3), dtype=np.uint64)
+    ak = rng.integers(0, q, size=(w + 1, 2, d3, n3), dtype=np.uint64)
+    f = rng.integers(0, q, size=n3, dtype=np.uint64)
+    ts, x = [], 1
+    for _ in range(w):
+        x = x * 5 %% (2 * n3); ts.append(x if x < n3 else x - 2 * n3)
+    ts = [-5] + ts
+    tot3 = 5
+    lwe_a = rng.integers(0, n3, size=(tot3, nl3), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    lwe_b = rng.integers(0, 2 * n3, size=tot3, dtype=np.uint64)
+    rot = lambda i: np.concatenate(cref.blind_rotate(q, n3, w, lb3, d3, lb3, d3, brk, ak, ts, f, lwe_a[i], int(lwe_b[i])))
+    lo, hi = shard_range(tot3, rank, world)
+    width = -(-tot3 // world)
+    pad = np.zeros((width, 2 * n3), dtype=np.uint64)
+    for j, i in enumerate(range(lo, hi)):
+        pad[j] = rot(i)
+    out = gather_results(T(pad)).numpy().view(np.uint64)
+    rows = [out[r * width: r * width + (shard_range(tot3, r, world)[1] - shard_range(tot3, r, world)[0])] for r in range(world)]
+    assert np.array_equal(np.concatenate(rows, axis=0), np.stack([rot(i) for i in range(tot3)])), "sharded blind rotations != single-process result"
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_two_rank_gloo_sharded_bootstraps(tmp_path):
+    """SURVEY.md section 8(e) row 2 (cfg3 / cfg5): a batch of bootstraps split across ranks with the helper bench.py uses, keys
+    replicated, no data-path collective, final gather of the outputs; ragged batches (7 over 2, 5 over 2)"""
+    script = tmp_path / "bootstrap_worker.py"
+    script.write_text(BOOTSTRAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
