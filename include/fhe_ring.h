@@ -251,6 +251,33 @@ int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_
                        const uint64_t *ksk_b, const uint64_t *v, const uint64_t *lwe_a, const uint64_t *lwe_b, uint64_t *out_a,
                        uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
 
+/* ---- key material on the device ------------------------------------------------- */
+/* Randomness: value i of a draw is a word of ChaCha20 block (i / words per block) under a key expanded from `seed`, nonce
+ * `stream_id` -- counter based, reproducible, order independent.  The reference draws from `thread_rng()`; draws are not
+ * parity relevant, these entry points are validated at decrypt level and statistically. */
+/* util/src/zq.rs:91-93 `Zq::sample_uniform`: `count` values uniform in [0, q) */
+int fhe_sample_uniform(uint64_t q, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+/* util/src/torus.rs `T64::sample_uniform`: uniform 64-bit torus values */
+int fhe_sample_torus(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+/* util/src/misc/distribution.rs:23-46 `dg(std_dev, n)` (weights from the reference's erf approximation, support
+ * [-floor(n std_dev), floor(n std_dev)]) as `Zq::sample_i64` (zq.rs:95-97); q = 0: plain two's-complement integers */
+int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
+                  void *stream);
+/* util/src/misc/decompose.rs:35-40 `power_up`: out[p][j] = in[p] * 2^(rounding_bits + j log_b) mod q, [polys][d][n] */
+int fhe_power_up(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rlwe.rs:146-156 `Rlwe::sk_encrypt` for `batch` plaintexts (pt [batch][n] or NULL = zeros): a uniform,
+ * e <- dg(3.2, 6), b = a sk + e + pt.  sk [n]: the secret key as Zq values (`Zq::from_i64` of its coefficients). */
+int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
+                        uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rgsw.rs:84-105 `Rgsw::sk_encrypt` of `count` plaintext polynomials (pt [count][n], `Rgsw::encode`d):
+ * rows_a / rows_b [count][2d][n], the layout fhe_rgsw_prepare takes. */
+int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count,
+                     uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+/* scheme/fhew/src/rlwe.rs:109-120 `Rlwe::ksk_gen(param, sk0, sk1)` (t = 0) and 122-132 `Rlwe::ak_gen(param, t, sk0)` (t != 0,
+ * sk1 ignored: the key switches sk0(X^t) back to sk0): rows_a / rows_b [d][n], the layout fhe_ksk_prepare takes. */
+int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n,
+                     uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

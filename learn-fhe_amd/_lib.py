@@ -121,6 +121,13 @@ def lib():
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
+        L.fhe_sample_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_sample_torus.argtypes = [C.c_uint64, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_sample_dg.argtypes = [C.c_uint64, C.c_double, ci, C.c_uint64, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_power_up.argtypes = [C.c_uint64, ci, ci, vp, sz, sz, vp, ci, vp]
+        L.fhe_rlwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_rgsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_rlwe_ksk_gen.argtypes = [vp, ci, ci, vp, vp, C.c_int64, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
         L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib

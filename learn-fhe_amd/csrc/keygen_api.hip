@@ -1,0 +1,259 @@
+// extern "C" entry points of the key-material producers: samplers, power_up, RLWE secret-key
+// encryption, RGSW / key-switching / automorphism key generation, all on the device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/fhe_ring.h"
+#include "api_common.hpp"
+#include "ctx.hpp"
+#include "keygen_kernels.hpp"
+
+using fhe::u64;
+
+namespace {
+inline unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
+}
+
+// distribution.rs:25-45, evaluated on the host exactly as the reference does
+int make_dg_table(double std_dev, int n_sigma, fhe::DgTable *T) {
+    if (!(std_dev > 0) || n_sigma < 1) return FHE_ERR_INVALID;
+    auto erf_as = [](double x) {
+        const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
+        const double t = 1.0 / (1.0 + p * std::fabs(x));
+        const double pos = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+        return std::signbit(x) ? -pos : pos;
+    };
+    auto cdf = [&](double x) { return (1.0 + erf_as(x / (std_dev * 1.4142135623730951))) / 2.0; };
+    const long long mx = (long long)std::floor((double)n_sigma * std_dev);
+    if (mx < 0 || 2 * mx + 1 > fhe::DG_MAX_TABLE) return FHE_ERR_UNSUPPORTED;
+    T->max = (int)mx; T->len = (int)(2 * mx + 1);
+    double acc = 0;
+    for (long long i = -mx; i <= mx; ++i) {
+        acc += cdf((double)i + 0.5) - cdf((double)i - 0.5);
+        T->cum[i + mx] = acc;
+    }
+    return FHE_OK;
+}
+
+// blocks of the generator a draw of `count` values occupies: callers advance `first` by this to chain independent draws on one stream id
+inline unsigned long long blocks_uniform(size_t count) { return (count + 3) / 4; }
+inline unsigned long long blocks_words(size_t count) { return (count + 7) / 8; }
+
+int sample_uniform_dev(u64 q, const fhe::ChaChaKey &K, unsigned long long first, u64 *out, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(fhe::sample_uniform_kernel, dim3(grid_for(blocks_uniform(count))), dim3(256), 0, st, out, count, fhe::make_barrett(q), K, first);
+    return hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+}
+int sample_dg_dev(u64 q, const fhe::DgTable &T, const fhe::ChaChaKey &K, unsigned long long first, u64 *out, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(fhe::sample_dg_kernel, dim3(grid_for(blocks_words(count))), dim3(256), 0, st, out, count, q, T, K, first);
+    return hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+}
+
+// rlwe.rs:146-156 for `rows` ciphertexts under one secret key, device buffers: a uniform, e <- dg(3.2, 6), b = a sk + e + pt
+// (pt: [pt_rows][n] cycled, or null for encryptions of zero).  sk_eval: the secret key in the evaluation domain.
+int rlwe_sk_encrypt_dev(const fhe_ctx *ctx, const u64 *sk_eval, const u64 *pt, size_t pt_rows, u64 *ct_a, u64 *ct_b, size_t n, size_t rows,
+                        const fhe::ChaChaKey &K, unsigned long long *cursor, hipStream_t st) {
+    const size_t count = rows * n;
+    const int log_n = ilog2(n);
+    fhe::DgTable T;
+    int rc = make_dg_table(3.2, 6, &T);
+    if (rc != FHE_OK) return rc;
+    StreamWs we(count * sizeof(u64), st);
+    if (we.rc != FHE_OK) return we.rc;
+    u64 *e = we.as<u64>();
+    rc = sample_uniform_dev(ctx->q, K, *cursor, ct_a, count, st);
+    *cursor += blocks_uniform(count);
+    if (rc == FHE_OK) rc = sample_dg_dev(ctx->q, T, K, *cursor, e, count, st);
+    *cursor += blocks_words(count);
+    // b = a * sk: forward transform of a out of place into b, inverse with the (broadcast) evaluation-domain key on its load
+    if (rc == FHE_OK && n > 1) {
+        fhe::NttIo src;
+        src.src = ct_a; src.src_mod = (unsigned)rows;
+        rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, ct_b, log_n, rows, st, ctx->pm_b, src);
+        if (rc == FHE_OK) {
+            fhe::NttIo mul;
+            mul.mul = sk_eval; mul.mul_div = (unsigned)rows; mul.mul_period = 1;
+            rc = fhe::ntt_inv_multi(ctx->d_desc, 1, ct_b, log_n, rows, st, ctx->pm_b, mul);
+        }
+    } else if (rc == FHE_OK) {
+        return FHE_ERR_UNSUPPORTED;
+    }
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::add3_kernel, dim3(grid_for(count)), dim3(256), 0, st, ct_b, (const u64 *)e, pt, count, pt ? pt_rows * n : 1, (u64)ctx->q);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc;
+}
+
+int check_ring(const fhe_ctx *ctx, size_t n) {
+    if (!ctx || !is_pow2(n) || n < 2) return FHE_ERR_INVALID;
+    if (ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    const int log_n = ilog2(n);
+    if (log_n > ctx->s - 1) return FHE_ERR_NO_ROOT;
+    if (log_n > ctx->log_cap) return FHE_ERR_UNSUPPORTED;
+    return FHE_OK;
+}
+
+int gadget_geometry(u64 q, int log_b, int d, int *rounding_bits) {
+    if (q < 2 || log_b < 1 || log_b > 62 || d < 1 || d > 64) return FHE_ERR_INVALID;
+    const int log_q = q <= 1 ? 0 : 64 - __builtin_clzll(q - 1);  // q.next_power_of_two().ilog2() (decompose.rs:49-64)
+    *rounding_bits = log_q - log_b * d > 0 ? log_q - log_b * d : 0;
+    return FHE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fhe_sample_uniform(uint64_t q, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || (!out && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    int rc = sample_uniform_dev(q, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    return rc == FHE_OK ? mo.sync_out(st) : rc;
+}
+
+int fhe_sample_torus(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!out && count) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(blocks_words(count))), dim3(256), 0, st, mo.d, count, fhe::chacha_key(seed, stream_id), 0ull);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
+                  void *stream) {
+    if ((q >> 62) || q == 1 || (!out && count)) return FHE_ERR_INVALID;
+    fhe::DgTable T;
+    int rc = make_dg_table(std_dev, n_sigma, &T);
+    if (rc != FHE_OK) return rc;
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    rc = sample_dg_dev(q, T, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    return rc == FHE_OK ? mo.sync_out(st) : rc;
+}
+
+int fhe_power_up(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream) {
+    int rb = 0;
+    int rc = gadget_geometry(q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if ((q >> 62) || ((!in || !out) && n * polys)) return FHE_ERR_INVALID;
+    if (n * polys == 0) return FHE_OK;
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, n * polys, mem, true, st), mo(out, n * polys * d, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::power_up_kernel, dim3(grid_for(n * polys * d)), dim3(256), 0, st, (const u64 *)mi.d, mo.d, n, polys, d, rb, log_b,
+                       fhe::make_barrett(q), 0);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed, uint64_t stream_id,
+                        uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+    int rc = check_ring(ctx, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || ((!ct_a || !ct_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? n * batch : 0, mem, true, st), ma(ct_a, n * batch, mem, false, st), mb(ct_b, n * batch, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs wsk(n * sizeof(u64), st);
+    if (wsk.rc != FHE_OK) return wsk.rc;
+    fhe::NttIo src;
+    src.src = msk.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, wsk.as<u64>(), ilog2(n), 1, st, ctx->pm_b, src);
+    unsigned long long cursor = 0;
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, wsk.as<u64>(), pt ? mpt.d : nullptr, batch, ma.d, mb.d, n, batch, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// rgsw.rs:84-105 for `count` plaintext polynomials under one secret key: rows_a / rows_b [count][2d][n]
+int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, uint64_t seed,
+                     uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    int rc = check_ring(ctx, n), rb = 0;
+    if (rc == FHE_OK) rc = gadget_geometry(ctx->q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if (!sk || ((!pt || !rows_a || !rows_b) && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * 2 * d;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, n * count, mem, true, st), ma(rows_a, rows * n, mem, false, st), mb(rows_b, rows * n, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs ws((n + count * d * n) * sizeof(u64), st);  // sk in the evaluation domain | power_up(pt): [count][d][n]
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *sk_eval = ws.as<u64>(), *pw = sk_eval + n;
+    fhe::NttIo src;
+    src.src = msk.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, sk_eval, ilog2(n), 1, st, ctx->pm_b, src);
+    unsigned long long cursor = 0;
+    // 2d encryptions of zero per plaintext (rgsw.rs:91-99) ...
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, nullptr, 0, ma.d, mb.d, n, rows, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::power_up_kernel, dim3(grid_for(n * count * d)), dim3(256), 0, st, (const u64 *)mpt.d, pw, n, count, d, rb, log_b,
+                           fhe::make_barrett(ctx->q), 0);
+        // ... rows 0..d: a += pt base_j; rows d..2d: b += pt base_j (rgsw.rs:100-103)
+        for (size_t c = 0; c < count && rc == FHE_OK; ++c) {
+            hipLaunchKernelGGL(fhe::add_assign_kernel, dim3(grid_for(d * n)), dim3(256), 0, st, ma.d + c * 2 * d * n, (const u64 *)(pw + c * d * n), (size_t)d * n, (u64)ctx->q);
+            hipLaunchKernelGGL(fhe::add_assign_kernel, dim3(grid_for(d * n)), dim3(256), 0, st, mb.d + (c * 2 * d + d) * n, (const u64 *)(pw + c * d * n), (size_t)d * n, (u64)ctx->q);
+        }
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// rlwe.rs:109-132: key-switching key sk1 -> sk0 (rows encrypt -sk1 base_j under sk0); t != 0: automorphism key, sk1 = sk0(X^t)
+int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n, uint64_t seed,
+                     uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    int rc = check_ring(ctx, n), rb = 0;
+    if (rc == FHE_OK) rc = gadget_geometry(ctx->q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if (!sk0 || (!sk1 && t == 0) || !rows_a || !rows_b) return FHE_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror m0(sk0, n, mem, true, st), m1(t == 0 ? sk1 : sk0, n, mem, true, st), ma(rows_a, d * n, mem, false, st), mb(rows_b, d * n, mem, false, st);
+    if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs ws((2 * n + d * n) * sizeof(u64), st);  // sk0 evaluation domain | sk1 (or its automorphism) | power_up(-sk1)
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *sk_eval = ws.as<u64>(), *s1 = sk_eval + n, *pw = s1 + n;
+    fhe::NttIo src;
+    src.src = m0.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, sk_eval, ilog2(n), 1, st, ctx->pm_b, src);
+    if (rc == FHE_OK && t != 0) rc = fhe_automorphism(ctx->q, t, (const uint64_t *)m0.d, (uint64_t *)s1, n, 1, FHE_MEM_DEVICE, stream);  // rlwe.rs:129
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::power_up_kernel, dim3(grid_for(n * d)), dim3(256), 0, st, (const u64 *)(t != 0 ? s1 : m1.d), pw, n, (size_t)1, d, rb, log_b,
+                           fhe::make_barrett(ctx->q), 1);  // power_up(-sk1)
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    unsigned long long cursor = 0;
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, pw, d, ma.d, mb.d, n, d, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+}  // extern "C"

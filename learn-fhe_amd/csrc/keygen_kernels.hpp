@@ -1,0 +1,132 @@
+// Key-material producers on the device: a counter-based generator and the reference's
+// samplers, so that bootstrapping / key-switching keys are built in HBM where the hot path consumes them.
+//
+// Randomness.  The reference draws from `thread_rng()` (ChaCha12 behind a thread-local handle), one value after another; a
+// GPU needs every lane to find ITS value without a shared state.  Here value i of a draw is word (i mod 8) of ChaCha20 block
+// (i div 8) under a 256-bit key expanded from the caller's seed and a 64-bit stream id as the nonce (RFC 8439 block function,
+// 64-bit block counter): reproducible, order independent, and a CSPRNG as the reference's generator is.  Draws are NOT
+// parity-relevant (the reference's are unseeded): these producers are validated at decrypt level and statistically.
+#pragma once
+#include "arith.hpp"
+
+namespace fhe {
+
+struct ChaChaKey {
+    unsigned k[8];
+    unsigned nonce[2];
+};
+
+__host__ __device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
+
+#define FHE_CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+
+// one 64-byte block as eight u64 words
+__host__ __device__ inline void chacha20_block(const ChaChaKey &K, unsigned long long counter, unsigned long long (&out)[8]) {
+    unsigned s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, K.k[0], K.k[1], K.k[2], K.k[3], K.k[4], K.k[5], K.k[6], K.k[7],
+                      (unsigned)counter, (unsigned)(counter >> 32), K.nonce[0], K.nonce[1]};
+    unsigned x[16];
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
+    for (int r = 0; r < 10; ++r) {
+        FHE_CHACHA_QR(x[0], x[4], x[8], x[12]) FHE_CHACHA_QR(x[1], x[5], x[9], x[13]) FHE_CHACHA_QR(x[2], x[6], x[10], x[14]) FHE_CHACHA_QR(x[3], x[7], x[11], x[15])
+        FHE_CHACHA_QR(x[0], x[5], x[10], x[15]) FHE_CHACHA_QR(x[1], x[6], x[11], x[12]) FHE_CHACHA_QR(x[2], x[7], x[8], x[13]) FHE_CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 8; ++i) out[i] = (unsigned long long)(x[2 * i] + s[2 * i]) | ((unsigned long long)(x[2 * i + 1] + s[2 * i + 1]) << 32);
+}
+
+// seed -> 256-bit key (SplitMix64 expansion: the seed is the caller's entropy, 64 bits of it; a 256-bit entry point is one line away)
+inline ChaChaKey chacha_key(unsigned long long seed, unsigned long long stream_id) {
+    ChaChaKey K;
+    unsigned long long z = seed;
+    for (int i = 0; i < 4; ++i) {
+        z += 0x9E3779B97F4A7C15ull;
+        unsigned long long v = z;
+        v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull; v = (v ^ (v >> 27)) * 0x94D049BB133111EBull; v ^= v >> 31;
+        K.k[2 * i] = (unsigned)v; K.k[2 * i + 1] = (unsigned)(v >> 32);
+    }
+    K.nonce[0] = (unsigned)stream_id; K.nonce[1] = (unsigned)(stream_id >> 32);
+    return K;
+}
+
+// util/src/zq.rs:91-93 `Zq::sample_uniform` (rand's `Uniform::new(0, q)`): uniform in [0, q).  Two 64-bit words per value, reduced
+// as a 128-bit integer: bias below 2^-64 (rand's own sampler rejects instead; both are exact to any observable precision).
+FHE_HEADER_KERNEL void sample_uniform_kernel(u64 *__restrict__ out, size_t count, Barrett B, ChaChaKey K, unsigned long long first) {
+    const u64 two64 = (u64)((((unsigned __int128)1) << 64) % B.q);  // per thread, set-up code
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 4 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = blk * 4 + j;
+            if (i < count) {
+                const u64 hi = w[2 * j] % B.q, lo = w[2 * j + 1] % B.q;
+                out[i] = csub(mulmod_barrett(hi, two64, B) + lo, B.q);
+            }
+        }
+    }
+}
+// torus values: uniform u64 (util/src/torus.rs `T64::sample_uniform`)
+FHE_HEADER_KERNEL void sample_u64_kernel(u64 *__restrict__ out, size_t count, ChaChaKey K, unsigned long long first) {
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 8 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (blk * 8 + j < count) out[blk * 8 + j] = w[j];
+    }
+}
+
+// util/src/misc/distribution.rs:23-46 `dg(std_dev, n)`: integers in [-max, max], max = floor(n std_dev), weight of i =
+// cdf(i + 0.5) - cdf(i - 0.5) with the reference's erf approximation (Abramowitz-Stegun 7.1.26); `WeightedIndex` = inverse
+// transform on the cumulative weights, which the host tabulates (cum[j] = sum of the first j + 1 weights, cum[2 max] = total).
+// Output as `Zq::from_i64` (zq.rs:63-69) when q != 0, as two's-complement i64 otherwise.
+constexpr int DG_MAX_TABLE = 129;
+struct DgTable {
+    double cum[DG_MAX_TABLE];
+    int len, max;
+};
+FHE_HEADER_KERNEL void sample_dg_kernel(u64 *__restrict__ out, size_t count, u64 q, DgTable T, ChaChaKey K, unsigned long long first) {
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 8 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t i = blk * 8 + j;
+            if (i >= count) continue;
+            const double u = (double)(w[j] >> 11) * (1.0 / 9007199254740992.0) * T.cum[T.len - 1];  // [0, total)
+            int idx = 0;
+            while (idx < T.len - 1 && u >= T.cum[idx]) ++idx;
+            const long long v = (long long)idx - T.max;
+            out[i] = q ? (v < 0 ? q - (u64)(-v) % q : (u64)v % q) % q : (u64)v;
+        }
+    }
+}
+
+// util/src/misc/decompose.rs:35-40 `power_up`: out[p][j][i] = in[p][i] * base_j mod q, base_j = 2^(rounding_bits + j log_b) mod q
+FHE_HEADER_KERNEL void power_up_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, size_t polys, int d, int rounding_bits, int log_b,
+                                       Barrett B, int negate) {
+    const size_t total = n * polys * d;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t i = idx % n, j = (idx / n) % d, p = idx / (n * d);
+        u64 base = 1;  // 2^(rb + j log_b) mod q by repeated doubling (d, log_b small: set-up code)
+        for (int s = 0; s < rounding_bits + (int)j * log_b; ++s) base = csub(base + base, B.q);
+        u64 v = in[p * n + i];
+        if (negate) v = v ? B.q - v : 0;
+        out[idx] = mulmod_barrett(v, base, B);
+    }
+}
+
+// b <- b + e + pt (rlwe.rs:153), optionally pt = 0 (null)
+FHE_HEADER_KERNEL void add3_kernel(u64 *__restrict__ b, const u64 *__restrict__ e, const u64 *__restrict__ pt, size_t count, size_t pt_mod, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) {
+        u64 v = csub(b[i] + e[i], q);
+        if (pt) v = csub(v + pt[i % pt_mod], q);
+        b[i] = v;
+    }
+}
+// out[i] += add[i] over a strided set of polynomials (rgsw.rs:101-103: `ct.0 += pt` on rows 0..d, `ct.1 += pt` on rows d..2d)
+FHE_HEADER_KERNEL void add_assign_kernel(u64 *__restrict__ out, const u64 *__restrict__ add, size_t count, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) out[i] = csub(out[i] + add[i], q);
+}
+
+}  // namespace fhe

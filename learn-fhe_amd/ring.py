@@ -569,3 +569,73 @@ class Fhew:
     def xor(self, c0, c1): return self._op("xor", [2, -2], [c0, c1])          # noqa: E704
     def xnor(self, c0, c1): return self._op("xnor", [2, -2], [c0, c1])        # noqa: E704
     def majority(self, c0, c1, c2): return self._op("majority", [1, 1, 1], [c0, c1, c2])  # noqa: E704
+
+
+# ---- key material on the device ------------------------------------------------------------------
+
+
+def sample_uniform(q, seed, stream_id, like, shape):
+    """util/src/zq.rs:91-93: uniform in [0, q); `like` picks host (numpy) or device (torch) output."""
+    out = _like(like, tuple(shape))
+    p, cnt, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_uniform(q, seed, stream_id, p, cnt, mem, st), "fhe_sample_uniform")
+    return out
+
+
+def sample_torus(seed, stream_id, like, shape):
+    out = _like(like, tuple(shape))
+    p, cnt, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_torus(seed, stream_id, p, cnt, mem, st), "fhe_sample_torus")
+    return out
+
+
+def sample_dg(q, std_dev, n_sigma, seed, stream_id, like, shape):
+    """util/src/misc/distribution.rs:23-46 `dg(std_dev, n)` as Zq values (q = 0: two's-complement integers)."""
+    out = _like(like, tuple(shape))
+    p, cnt, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_dg(q, float(std_dev), n_sigma, seed, stream_id, p, cnt, mem, st), "fhe_sample_dg")
+    return out
+
+
+def power_up(q, log_b, d, a, n):
+    """util/src/misc/decompose.rs:35-40: [polys][n] -> [polys][d][n]."""
+    p, cnt, mem, st = _buf(a)
+    polys = cnt // n
+    out = _like(a, (polys, d, n))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_power_up(q, log_b, d, p, n, polys, po, mem, st), "fhe_power_up")
+    return out
+
+
+def rlwe_sk_encrypt(ctx: NttContext, sk, pt, n, batch, seed, stream_id):
+    """scheme/fhew/src/rlwe.rs:146-156; sk [n] as Zq values, pt [batch][n] or None (zeros) -> (a, b)."""
+    ps, _, mem, st = _buf(sk)
+    pp = _buf(pt)[0] if pt is not None else None
+    a, b = _like(sk, (batch, n)), _like(sk, (batch, n))
+    pa, _, _, _ = _buf(a)
+    pb, _, _, _ = _buf(b)
+    L.check(L.lib().fhe_rlwe_sk_encrypt(ctx.handle, ps, pp, n, batch, seed, stream_id, pa, pb, mem, st), "fhe_rlwe_sk_encrypt")
+    return a, b
+
+
+def rgsw_encrypt(ctx: NttContext, log_b, d, sk, pt, n, seed, stream_id):
+    """scheme/fhew/src/rgsw.rs:84-105; pt [count][n] -> (rows_a, rows_b) [count][2d][n]."""
+    ps, _, mem, st = _buf(sk)
+    pp, cnt, _, _ = _buf(pt)
+    count = cnt // n
+    ra, rb = _like(sk, (count, 2 * d, n)), _like(sk, (count, 2 * d, n))
+    pa, _, _, _ = _buf(ra)
+    pb, _, _, _ = _buf(rb)
+    L.check(L.lib().fhe_rgsw_encrypt(ctx.handle, log_b, d, ps, pp, n, count, seed, stream_id, pa, pb, mem, st), "fhe_rgsw_encrypt")
+    return ra, rb
+
+
+def rlwe_ksk_gen(ctx: NttContext, log_b, d, sk0, sk1, t, n, seed, stream_id):
+    """scheme/fhew/src/rlwe.rs:109-132: t = 0: key-switching key sk1 -> sk0; t != 0: automorphism key of sk0 for X -> X^t."""
+    p0, _, mem, st = _buf(sk0)
+    p1 = _buf(sk1)[0] if sk1 is not None else None
+    ra, rb = _like(sk0, (d, n)), _like(sk0, (d, n))
+    pa, _, _, _ = _buf(ra)
+    pb, _, _, _ = _buf(rb)
+    L.check(L.lib().fhe_rlwe_ksk_gen(ctx.handle, log_b, d, p0, p1, t, n, seed, stream_id, pa, pb, mem, st), "fhe_rlwe_ksk_gen")
+    return ra, rb

@@ -1,0 +1,131 @@
+"""key material produced on the device -- samplers (util/src/misc/distribution.rs, zq.rs:91-97),
+`power_up` (decompose.rs:35-40), `Rlwe::sk_encrypt` (rlwe.rs:146-156), `Rgsw::sk_encrypt` (rgsw.rs:84-105), `Rlwe::ksk_gen` /
+`ak_gen` (rlwe.rs:109-132).  The reference's draws come from `thread_rng()`: no parity exists for them, so -- exactly as the
+reference tests its own key generation -- the producers are checked at DECRYPT level (the reference's rgsw.rs:198-211 and
+rlwe.rs:379-415 tests, run with keys made on the device), statistically, and for determinism; `power_up` is bit-exact."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = lambda x: [int(v) for v in np.asarray(x).ravel()]  # noqa: E731
+U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_samplers(fhe, torch_cuda):
+    like = dev(torch_cuda, U([0]))
+    q = 18014398509404161
+    n = 1 << 16
+    u = host(fhe.sample_uniform(q, 7, 1, like, (n,)))
+    assert u.max() < q and abs(float(u.astype(np.float64).mean()) / q - 0.5) < 0.01
+    assert len(np.unique(u)) > n - 4
+    assert np.array_equal(u, host(fhe.sample_uniform(q, 7, 1, like, (n,))))                # reproducible
+    assert not np.array_equal(u, host(fhe.sample_uniform(q, 7, 2, like, (n,))))            # another stream
+    assert np.array_equal(u[:1000], host(fhe.sample_uniform(q, 7, 1, like, (1000,))))      # order independent: a prefix is a prefix
+    assert np.array_equal(u[:77], fhe.sample_uniform(q, 7, 1, U([0]), (77,)))              # host-memory call: same values
+    small = host(fhe.sample_uniform(5, 3, 0, like, (50000,)))
+    assert small.max() == 4 and all(abs(int((small == v).sum()) - 10000) < 600 for v in range(5))
+    t = host(fhe.sample_torus(9, 0, like, (n,)))
+    assert abs(float((t >> np.uint64(63)).mean()) - 0.5) < 0.01 and len(np.unique(t)) == n
+    # dg(3.2, 6): support [-19, 19], variance ~ 3.2^2, symmetric; as Zq values and as plain integers
+    e = host(fhe.sample_dg(0, 3.2, 6, 11, 0, like, (n,))).view(np.int64)
+    assert e.min() >= -19 and e.max() <= 19
+    assert abs(float(e.mean())) < 0.05 and abs(float(e.var()) - 3.2 ** 2) < 0.3
+    ez = host(fhe.sample_dg(q, 3.2, 6, 11, 0, like, (n,)))
+    assert np.array_equal(ez, np.where(e < 0, q - (-e), e).astype(np.uint64))
+    # the weights are the reference's: cdf differences with the A&S 7.1.26 erf
+    def erf_as(x):
+        p, a1, a2, a3, a4, a5 = 0.3275911, 0.254829592, -0.284496736, 1.421413741, -1.453152027, 1.061405429
+        tt = 1.0 / (1.0 + p * abs(x))
+        pos = 1.0 - (((((a5 * tt + a4) * tt) + a3) * tt + a2) * tt + a1) * tt * math.exp(-x * x)
+        return pos if x >= 0 else -pos
+    cdf = lambda x: (1.0 + erf_as(x / (3.2 * math.sqrt(2)))) / 2.0  # noqa: E731
+    w = [cdf(i + 0.5) - cdf(i - 0.5) for i in range(-19, 20)]
+    big = host(fhe.sample_dg(0, 3.2, 6, 12, 0, like, (1 << 20,))).view(np.int64)
+    for i in (-6, -1, 0, 1, 3, 9):
+        exp = w[i + 19] / sum(w) * (1 << 20)
+        assert abs(int((big == i).sum()) - exp) < 6 * math.sqrt(exp) + 5, i
+
+
+def test_power_up_bit_exact(fhe, torch_cuda):
+    from oracle import pyref as P
+    rnd = random.Random(5)
+    for q, log_b, d in [(18014398509404161, 6, 9), (268409857, 7, 4), (35184372065281, 5, 9), (1 << 16, 4, 4)]:
+        dec = P.Base2Decomposor(q, log_b, d)
+        v = [[rnd.randrange(q) for _ in range(16)] for _ in range(3)]
+        out = host(fhe.power_up(q, log_b, d, dev(torch_cuda, U(v)), 16)).reshape(3, d, 16)
+        for p in range(3):
+            assert out[p].tolist() == dec.power_up_poly(v[p])
+
+
+def test_device_made_keys_decrypt_level(fhe, torch_cuda):
+    """rgsw.rs:198-211 (external product), rlwe.rs:345-351 (encrypt/decrypt), rlwe.rs:379-415 (key switch, automorphism) with every
+    ciphertext and key produced by the device-side generators; decryption by the oracle"""
+    from oracle import pyref as P
+    rnd = random.Random(31)
+    log_n, p, log_b, d = 7, 16, 5, 9
+    n = 1 << log_n
+    q = next(P.two_adic_primes(45, log_n + 1))
+    delta = q / p
+    enc = lambda m: [P.zq_from_f64(q, float(x) * delta) for x in m]  # noqa: E731
+    decd = lambda pt: [P.zq_from_f64(p, float(P.zq_to_i64(q, x)) / delta) for x in pt]  # noqa: E731
+    ctx = fhe.NttContext(q)
+    like = dev(torch_cuda, U([0]))
+    # secret keys: dg(3.2, 6) on the device (rlwe.rs:94-96)
+    sk_z = fhe.sample_dg(q, 3.2, 6, 100, 0, like, (n,))
+    sk2_z = fhe.sample_dg(q, 3.2, 6, 100, 1, like, (n,))
+    sk = [P.zq_to_i64(q, v) for v in L(host(sk_z))]
+    sk2 = [P.zq_to_i64(q, v) for v in L(host(sk2_z))]
+    assert max(abs(v) for v in sk) <= 19
+    m0, m1 = [rnd.randrange(p) for _ in range(n)], [rnd.randrange(p) for _ in range(n)]
+    # encrypt / decrypt
+    ca, cb = fhe.rlwe_sk_encrypt(ctx, sk_z, dev(torch_cuda, U([enc(m1), enc(m0)])), n, 2, 200, 0)
+    assert decd(P.rlwe_decrypt(q, sk, L(host(ca)[0]), L(host(cb)[0]))) == m1 and decd(P.rlwe_decrypt(q, sk, L(host(ca)[1]), L(host(cb)[1]))) == m0
+    za, zb = fhe.rlwe_sk_encrypt(ctx, sk_z, None, n, 3, 201, 0)   # encryptions of zero: the phase is the dg noise
+    for i in range(3):
+        ph = [P.zq_to_i64(q, x) for x in P.rlwe_decrypt(q, sk, L(host(za)[i]), L(host(zb)[i]))]
+        assert max(abs(x) for x in ph) <= 19 and any(ph)
+    assert not np.array_equal(host(za)[0], host(za)[1])
+    # RGSW(m0) made on the device, external product with RLWE(m1)
+    ra, rb = fhe.rgsw_encrypt(ctx, log_b, d, sk_z, dev(torch_cuda, U([m0, m1])), n, 300, 0)
+    rgsw = fhe.GadgetKey(ctx, log_b, d, ra, rb, n, rgsw=True)
+    a, b = ca[:1].clone(), cb[:1].clone()
+    rgsw.external_product_(0, a, b)
+    assert decd(P.rlwe_decrypt(q, sk, L(host(a)), L(host(b)))) == P.nega_cyclic_schoolbook_mul(p, m0, m1)
+    a, b = ca[:1].clone(), cb[:1].clone()
+    rgsw.external_product_(1, a, b)
+    assert decd(P.rlwe_decrypt(q, sk, L(host(a)), L(host(b)))) == P.nega_cyclic_schoolbook_mul(p, m1, m1)
+    # key switch sk2 -> sk: a ciphertext under sk2 decrypts under sk afterwards (rlwe.rs:379-391)
+    ka, kb = fhe.rlwe_ksk_gen(ctx, log_b, d, sk_z, sk2_z, 0, n, 400, 0)
+    ksk = fhe.GadgetKey(ctx, log_b, d, ka, kb, n, rgsw=False)
+    c2a, c2b = fhe.rlwe_sk_encrypt(ctx, sk2_z, dev(torch_cuda, U([enc(m1)])), n, 1, 401, 0)
+    ksk.key_switch_(0, c2a, c2b)
+    assert decd(P.rlwe_decrypt(q, sk, L(host(c2a)), L(host(c2b)))) == m1
+    # automorphism keys (rlwe.rs:401-415)
+    for t in (5, -5):
+        aa, ab = fhe.rlwe_ksk_gen(ctx, log_b, d, sk_z, None, t, n, 500 + t, 0)
+        ak = fhe.GadgetKey(ctx, log_b, d, aa, ab, n, rgsw=False)
+        a, b = ca[:1].clone(), cb[:1].clone()
+        ak.automorphism_(0, t, a, b)
+        assert decd(P.rlwe_decrypt(q, sk, L(host(a)), L(host(b)))) == P.automorphism(p, m1, t)
+    # host-memory operands take the same path
+    ha, hb = fhe.rgsw_encrypt(ctx, log_b, d, host(sk_z), U([m0, m1]), n, 300, 0)
+    assert np.array_equal(ha, host(ra).reshape(ha.shape)) and np.array_equal(hb, host(rb).reshape(hb.shape))
