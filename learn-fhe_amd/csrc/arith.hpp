@@ -251,7 +251,11 @@ struct ArithPM {
         return k;
     }
     // x mod~ q: < 2^B + 2^(64-B) c
-    static __device__ __forceinline__ u64 fold1(u64 x, const PmK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
+    static __device__ __forceinline__ u64 fold1(u64 x, const PmK &m) {
+        const unsigned hi = (unsigned)(x >> 32), h = hi >> (B - 32);
+        const u64 base = ((u64)(hi & (unsigned)(MASK >> 32)) << 32) | (unsigned)x;
+        return (u64)h * m.c + base;
+    }
     // x y mod~ q for two canonical variable operands (fused pointwise products): y is split like a twiddle; < q + eps
     static __device__ __forceinline__ u64 mulvar(u64 x, u64 y, const K &k) { return pm_mul<B>(x, split(y), k.m); }
     // Forward butterfly without any reduction.  Values grow by at most 2q per layer; a multiplicand must stay below 2^63
@@ -379,7 +383,13 @@ struct ArithDS {
         return (u64)(unsigned)(s1 >> 32) * m.c2 + v;
     }
     // x mod~ q: < 2^B + (x >> B) c
-    static __device__ __forceinline__ u64 fold1(u64 x, const DsK &m) { return (x & MASK) + (u64)(unsigned)(x >> B) * m.c; }
+    // (written on the two words: as `(x & MASK) + (x >> B) * c` hipcc builds the masked value in a fresh register pair and pays a
+    // v_mov per fold -- 224 of them in a 2^14 transform)
+    static __device__ __forceinline__ u64 fold1(u64 x, const DsK &m) {
+        const unsigned hi = (unsigned)(x >> 32), h = hi >> (B - 32);
+        const u64 base = ((u64)(hi & (unsigned)(MASK >> 32)) << 32) | (unsigned)x;
+        return (u64)h * m.c + base;
+    }
     static __device__ __forceinline__ u64 mul(u64 y, const uint4 &w, const DsK &m) { return fold1(mul_raw(y, w, m), m); }  // < q + 9c
     // two VARIABLE canonical operands: the second one has no precomputed w 2^32 mod q, so this is the one-operand product
     static __device__ __forceinline__ u64 mulvar(u64 x, u64 y, const K &k) {
