@@ -436,6 +436,24 @@ struct ArithDS {
     static __device__ __forceinline__ u64 fold(u64 x, const K &k) { return fold1(x, k.m); }
     static __device__ __forceinline__ u64 canon_fwd(u64 x, const K &k) { return csub(fold1(x, k.m), k.m.q); }
     static __device__ __forceinline__ u64 finish_inv(u64 x, const K &k) { return csub(mul(x, k.ninv, k.m), k.m.q); }
+    // Multiply-accumulate against VARIABLE key values (the fused gadget products): a key value has no precomputed w 2^32 mod q,
+    // so this is ArithPM's unreduced (v, u) accumulation on its 8-byte packed operands -- the transforms around it run on the
+    // two-operand product.  Forward outputs here are < (2 log2 N + 1) q, inside the bound ArithPM::mac states.
+    typedef typename ArithPM<B>::MacAcc MacAcc;
+    static constexpr int MAC_TERMS = ArithPM<B>::MAC_TERMS;
+    static __device__ __forceinline__ PmK pmk(const K &k) { return PmK{k.m.q, k.m.q2, k.m.q4, k.m.c, k.m.c2}; }
+    static __device__ __forceinline__ MacAcc mac_zero() { return MacAcc{0, 0}; }
+    static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }
+    static __device__ __forceinline__ MacAcc mac(MacAcc acc, u64 xin, u64 kval, int term, const K &k, const Barrett &) {
+        const unsigned wl = (unsigned)kval;
+        const PmTw w{wl, wl << (63 - B), (unsigned)(kval >> 32)};
+        u64 v, u;
+        pm_mul_vu<B>(xin, w, v, u);
+        acc.v += v; acc.u += u;
+        if ((term % MAC_TERMS) == MAC_TERMS - 1) acc = MacAcc{pm_reduce_vu<B>(acc.v, acc.u, pmk(k)), 0};
+        return acc;
+    }
+    static __device__ __forceinline__ u64 mac_finish(MacAcc acc, const K &k) { return pm_reduce_vu<B>(acc.v, acc.u, pmk(k)); }
 };
 
 // ---------------------------------------------------------------------------------------------------------

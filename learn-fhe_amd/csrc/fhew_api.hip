@@ -66,6 +66,15 @@ fhe::RingConsts ring_consts(const fhe_ctx *c, int) {
 
 // fused kernels are instantiated for Shoup arithmetic (any prime) at every supported degree and for the 54-bit
 // pseudo-Mersenne primes (BASELINE config 3's modulus) at N = 512 .. 2048
+// arithmetic of the fused kernels on cfg3's 54-bit moduli: -DFHE_FHEW_DS=0 keeps the single-operand product (A/B switch)
+#ifndef FHE_FHEW_DS
+#define FHE_FHEW_DS 1
+#endif
+#if FHE_FHEW_DS
+#define FHEW_POLICY54 fhe::ArithDS<54>
+#else
+#define FHEW_POLICY54 fhe::ArithPM<54>
+#endif
 inline bool use_pm54(const fhe_ctx *c, int log_n) { return c->pm_b == 54 && log_n >= 9; }
 
 #define FHEW_DISPATCH(log_n, ...)                                          \
@@ -270,9 +279,9 @@ static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bo
     }
     if (use_pm54(ctx, key->log_n)) {
         switch (key->log_n) {
-            case 9: GP_LAUNCH(fhe::ArithPM<54>, 9) break;
-            case 10: GP_LAUNCH_BIG(fhe::ArithPM<54>, 10) break;
-            case 11: GP_LAUNCH_BIG(fhe::ArithPM<54>, 11) break;
+            case 9: GP_LAUNCH(FHEW_POLICY54, 9) break;
+            case 10: GP_LAUNCH_BIG(FHEW_POLICY54, 10) break;
+            case 11: GP_LAUNCH_BIG(FHEW_POLICY54, 11) break;
             default: return FHE_ERR_UNSUPPORTED;
         }
     } else {
@@ -516,7 +525,7 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     }
     if (use_pm54(ctx, log_n)) {
         switch (log_n) {
-            BR_CASE(fhe::ArithPM<54>, 9) BR_CASE_BIG(fhe::ArithPM<54>, 10) BR_CASE_BIG(fhe::ArithPM<54>, 11)
+            BR_CASE(FHEW_POLICY54, 9) BR_CASE_BIG(FHEW_POLICY54, 10) BR_CASE_BIG(FHEW_POLICY54, 11)
             default: return fail(FHE_ERR_UNSUPPORTED);
         }
     } else {
