@@ -171,8 +171,8 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
         out["key_switches_per_sec_batch%d" % b] = b / dt
     # ct in 2L 8N + ksk 2(L+K) 8N + ct out 2L 8N = 16 MiB at cfg4
     out["roofline"] = roof(out["key_switches_per_sec_batch%d" % (8 * batch)], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
-                           "rns_extend + ntt_big_fwd_pass + ntt14w_fwd + ntt14w_inv (ksk products fused) + ntt_big_inv_pass + rns_rescale x2",
-                           "rings above 2^14 pay a second HBM round trip per transform (radix-2 pass + 2^14 sub-transforms)")
+                           "rns_extend + ntt14w_fwd<R0=4> + ntt14w_inv<R0=4> (2^15 rings in one pass; ksk products fused into the inverse's load) + rns_rescale x2",
+                           "the base conversions mix limbs, so extend / transforms / rescales stay separate passes over the limbs: ~4x the algorithmic bytes move")
     return out
 
 

@@ -1,4 +1,5 @@
-// N = 2^14 transform kernels, wave-local form (BASELINE config 2, and the sub-transforms of 2^15..2^17 rings).
+// N = 2^14 and N = 2^15 transform kernels, wave-local form (BASELINE configs 2 and 4; the 2^14 form also as the sub-transforms of
+// 2^16..2^17 rings).  Written out below for 2^14 (R0 = 3); R0 = 4 adds one layer to pass 0 and doubles the waves.
 //
 // A polynomial lives in the registers of a 512-thread workgroup (32 coefficients per thread, two workgroups per CU) as in
 // the first register-resident kernel, but the index bits are dealt so that after the first three layers every WAVE owns one
@@ -28,9 +29,14 @@
 namespace fhe {
 namespace w14 {
 
-constexpr int THREADS = 512;
+// R0 = layers of pass 0 = log2 of the waves per workgroup: 3 -> N = 2^14 (512 threads, two workgroups per CU), 4 -> N = 2^15
+// (1024 threads, one workgroup per CU, 136 KiB of LDS: a 2^15 ring in ONE pass over HBM instead of a radix-2 pass + two 2^14
+// sub-transforms).  Everything after X01 is the same code: a wave and its 2^11 block.
 constexpr int WSLOTS = 1088;                         // wave-private region: 1024 coefficients + padding, in u64 slots
-constexpr size_t LDS_BYTES = size_t(8) * WSLOTS * 8;  // 69 632 B -> two workgroups per CU; X01 uses the first 64 KiB of it
+template <int R0> constexpr int threads() { return 64 << R0; }
+template <int R0> constexpr size_t lds_bytes() { return (size_t(1) << R0) * WSLOTS * 8; }  // 69 632 B / 139 264 B; X01 uses the first 2^R0 x 8 KiB
+constexpr int THREADS = threads<3>();
+constexpr size_t LDS_BYTES = lds_bytes<3>();
 
 // A wave's LDS instructions execute in issue order: inside a wave-private exchange a read issued after a write sees it, and a
 // write issued after a read cannot overtake it.  All that is needed is that the COMPILER keeps the order (a workgroup-scope
@@ -76,17 +82,21 @@ __device__ unsigned long long g_stamps[4096][16];
 //   pass 2: x[(s << 4) | n4]     n4 = i[6:3],   s = i[2]
 //   pass 3: x[(ab << 3) | n3]    n3 = i[2:0],   ab = i[10:9]
 
-// pass 0 -> pass 1 (across waves; round h moves the coefficients with i[10] = h)
+// pass 0 -> pass 1 (across waves; round h moves the coefficients with i[10] = h).  Pass-0 register (pass, n): n = the top R0 index
+// bits, pass = the 5 - R0 bits below them (i[10] first; R0 = 3: (i10, i9), R0 = 4: i10); thread t = the remaining low bits.
+// Slot of a coefficient in the half image (bit 10 removed): (n << 10) | i[9:0]; lanes keep i[5:0]: conflict free unpadded.
+template <int R0>
 __device__ __forceinline__ void xchg_01(u64 (&x)[32], int t, int w, u64 *lds) {
+    constexpr int PB = 5 - R0, NLOW = 1 << (PB - 1);  // register bits below bit 10 (i9 for R0 = 3, none for R0 = 4)
     u64 *wp = lds + t, *rp = lds + (w << 10) + (t & 63);  // constant offsets from here on: immediates of the ds instructions
     u64 y[32];
     W14_PRIO_UP();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int b9 = 0; b9 < 2; ++b9)
+        for (int lo = 0; lo < NLOW; ++lo)
 #pragma unroll
-            for (int n3 = 0; n3 < 8; ++n3) wp[(n3 << 10) | (b9 << 9)] = x[((((h << 1) | b9)) << 3) | n3];
+            for (int n = 0; n < (1 << R0); ++n) wp[(n << 10) | (lo << (10 - (PB - 1)))] = x[((((h << (PB - 1)) | lo)) << R0) | n];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < 16; ++m) {  // m = (i9 i8 i7 i6)
@@ -100,7 +110,9 @@ __device__ __forceinline__ void xchg_01(u64 (&x)[32], int t, int w, u64 *lds) {
     for (int r = 0; r < 32; ++r) x[r] = y[r];
 }
 
+template <int R0>
 __device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, int w, u64 *lds) {
+    constexpr int PB = 5 - R0, NLOW = 1 << (PB - 1);
     u64 *rp = lds + t, *wp = lds + (w << 10) + (t & 63);
     u64 y[32];
     W14_PRIO_UP();
@@ -114,9 +126,9 @@ __device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, int w, u64 *lds) {
         }
         __syncthreads();
 #pragma unroll
-        for (int b9 = 0; b9 < 2; ++b9)
+        for (int lo = 0; lo < NLOW; ++lo)
 #pragma unroll
-            for (int n3 = 0; n3 < 8; ++n3) y[((((h << 1) | b9)) << 3) | n3] = rp[(n3 << 10) | (b9 << 9)];
+            for (int n = 0; n < (1 << R0); ++n) y[((((h << (PB - 1)) | lo)) << R0) | n] = rp[(n << 10) | (lo << (10 - (PB - 1)))];
         if (h == 0) __syncthreads();
     }
     W14_PRIO_DOWN();
@@ -211,33 +223,35 @@ __device__ __forceinline__ void xchg_32(u64 (&x)[32], int lane, u64 *wl) {
 }
 
 // units (arith.hpp): passes 0..2 are replicas sharing twiddles; pass 3 is one replica (i[10:9] = AB) at a time with its own
-template <int l> using P0 = Unit<0, 3, l, 0, 4, 8, true>;
-template <int l> using P1 = Unit<3, 4, l, 0, 2, 16, true>;
-template <int l> using P2 = Unit<7, 4, l, 0, 2, 16, true>;
-template <int l, int AB> using P3 = Unit<11, 3, l, AB, 1, 8, false, 6>;  // block prefix (w << 8) | (AB << 6) | lane
+template <int R0, int l> using P0 = Unit<0, R0, l, 0, (32 >> R0), (1 << R0), true>;
+template <int R0, int l> using P1 = Unit<R0, 4, l, 0, 2, 16, true>;
+template <int R0, int l> using P2 = Unit<R0 + 4, 4, l, 0, 2, 16, true>;
+template <int R0, int l, int AB> using P3 = Unit<R0 + 8, 3, l, AB, 1, 8, false, 6>;  // block prefix (w << 8) | (AB << 6) | lane
 
 // one replica's pass-3 twiddles (layers 11, 12, 13)
 template <class A>
 struct Tw7 {
     typename A::TwRaw l0[1], l1[2], l2[4];
 };
-template <class A, bool INV, int AB>
+template <class A, bool INV, int R0, int AB>
 __device__ __forceinline__ void tw7_load(Tw7<A> &b, int t3, const typename A::K &k) {
-    tw_load<A, INV, P3<0, AB>>(b.l0, t3, k);
-    tw_load<A, INV, P3<1, AB>>(b.l1, t3, k);
-    tw_load<A, INV, P3<2, AB>>(b.l2, t3, k);
+    tw_load<A, INV, P3<R0, 0, AB>>(b.l0, t3, k);
+    tw_load<A, INV, P3<R0, 1, AB>>(b.l1, t3, k);
+    tw_load<A, INV, P3<R0, 2, AB>>(b.l2, t3, k);
 }
 
-// HBM side of pass 0: register (s2, n3) <-> coefficient (n3 << 11) | (s2 << 9) | t, consecutive lanes on consecutive words
-template <int S2>
+// HBM side of pass 0: register (pass, n) <-> coefficient (n << 11) | (pass << (6 + R0)) | t, consecutive lanes on consecutive words
+template <int R0>
 __device__ __forceinline__ void load_p0(u64 (&x)[32], const u64 *__restrict__ g, int t) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int n = r & ((1 << R0) - 1), pass = r >> R0;
 #ifdef W14_ABLATE_NO_GLOBAL  // developer lab only: no HBM traffic
-#pragma unroll
-    for (int n3 = 0; n3 < 8; ++n3) x[S2 * 8 + n3] = (u64)(t + n3 + S2) * 0x9E3779B97F4A7C15ull >> 5;
+        x[r] = (u64)(t + r) * 0x9E3779B97F4A7C15ull >> 5;
 #else
-#pragma unroll
-    for (int n3 = 0; n3 < 8; ++n3) x[S2 * 8 + n3] = g[(n3 << 11) | (S2 << 9) | t];
+        x[r] = g[(n << 11) | (pass << (6 + R0)) | t];
 #endif
+    }
 }
 // HBM side of pass 3 (inverse loads): register (ab, n3) <-> coefficient (w << 11) | (ab << 9) | (lane << 3) | n3
 template <int AB>
@@ -293,46 +307,51 @@ __device__ __forceinline__ void store_p3(u64 (&x)[32], u64 *__restrict__ dst_wav
 }
 
 // One forward transform.  x[] arrives loaded (pass-0 layout, the loads possibly still in flight).
-template <class A>
+template <class A, int R0>
 __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
                                         const int t, const int lane, const int w) {
     typedef typename A::TwRaw Tw;
     STAMP_DECL;
     STAMP_REAL(10);
     STAMP(0);
-    {   // pass 0: layers 0..2, twiddles wave-uniform
-        Tw a0[1], a1[2], a2[4];
-        tw_load<A, false, P0<0>>(a0, 0, k); tw_load<A, false, P0<1>>(a1, 0, k); tw_load<A, false, P0<2>>(a2, 0, k);
+    {   // pass 0: layers 0..R0-1, twiddles wave-uniform
+        Tw a0[1], a1[2], a2[4], a3[8];
+        tw_load<A, false, P0<R0, 0>>(a0, 0, k); tw_load<A, false, P0<R0, 1>>(a1, 0, k); tw_load<A, false, P0<R0, 2>>(a2, 0, k);
+        if constexpr (R0 == 4) tw_load<A, false, P0<R0, (R0 == 4 ? 3 : 0)>>(a3, 0, k);
         STAMP(1);
         FHE_SCHED_FENCE();
-        ct_apply<A, P0<0>>(x, a0, k);
+        ct_apply<A, P0<R0, 0>>(x, a0, k);
         FHE_SCHED_FENCE();
-        ct_apply<A, P0<1>>(x, a1, k);
+        ct_apply<A, P0<R0, 1>>(x, a1, k);
         FHE_SCHED_FENCE();
-        ct_apply<A, P0<2>>(x, a2, k);
+        ct_apply<A, P0<R0, 2>>(x, a2, k);
+        if constexpr (R0 == 4) {
+            FHE_SCHED_FENCE();
+            ct_apply<A, P0<R0, (R0 == 4 ? 3 : 0)>>(x, a3, k);
+        }
     }
     FHE_SCHED_FENCE();
     Tw b0[1], b1[2], b2[4], b3[8];  // pass 1: wave-uniform as well (block prefix = w): fetched behind the barriers of X01
-    tw_load<A, false, P1<0>>(b0, w, k); tw_load<A, false, P1<1>>(b1, w, k); tw_load<A, false, P1<2>>(b2, w, k); tw_load<A, false, P1<3>>(b3, w, k);
+    tw_load<A, false, P1<R0, 0>>(b0, w, k); tw_load<A, false, P1<R0, 1>>(b1, w, k); tw_load<A, false, P1<R0, 2>>(b2, w, k); tw_load<A, false, P1<R0, 3>>(b3, w, k);
     STAMP(2);
-    xchg_01(x, t, w, lds);
+    xchg_01<R0>(x, t, w, lds);
     STAMP(3);
     if constexpr (A::PASS_FOLD) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
     }
     FHE_SCHED_FENCE();
-    ct_apply<A, P1<0>>(x, b0, k);
+    ct_apply<A, P1<R0, 0>>(x, b0, k);
     FHE_SCHED_FENCE();
-    ct_apply<A, P1<1>>(x, b1, k);
+    ct_apply<A, P1<R0, 1>>(x, b1, k);
     FHE_SCHED_FENCE();
-    ct_apply<A, P1<2>>(x, b2, k);
+    ct_apply<A, P1<R0, 2>>(x, b2, k);
     FHE_SCHED_FENCE();
-    ct_apply<A, P1<3>>(x, b3, k);
+    ct_apply<A, P1<R0, 3>>(x, b3, k);
     FHE_SCHED_FENCE();
     const int t2 = (w << 4) | (lane >> 2), t3 = (w << 8) | lane;
     Tw c0[1], c1[2], c2[4], c3[8];  // pass 2: per lane; the first seven ride through X12
-    tw_load<A, false, P2<0>>(c0, t2, k); tw_load<A, false, P2<1>>(c1, t2, k); tw_load<A, false, P2<2>>(c2, t2, k);
+    tw_load<A, false, P2<R0, 0>>(c0, t2, k); tw_load<A, false, P2<R0, 1>>(c1, t2, k); tw_load<A, false, P2<R0, 2>>(c2, t2, k);
     STAMP(4);
     xchg_12(x, lane, wl);
     STAMP(5);
@@ -341,17 +360,17 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
         for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
     }
     FHE_SCHED_FENCE();
-    ct_apply<A, P2<0>>(x, c0, k);
+    ct_apply<A, P2<R0, 0>>(x, c0, k);
     FHE_SCHED_FENCE();
-    ct_apply<A, P2<1>>(x, c1, k);
+    ct_apply<A, P2<R0, 1>>(x, c1, k);
     FHE_SCHED_FENCE();
-    tw_load<A, false, P2<3>>(c3, t2, k);
-    ct_apply<A, P2<2>>(x, c2, k);
+    tw_load<A, false, P2<R0, 3>>(c3, t2, k);
+    ct_apply<A, P2<R0, 2>>(x, c2, k);
     FHE_SCHED_FENCE();
-    ct_apply<A, P2<3>>(x, c3, k);
+    ct_apply<A, P2<R0, 3>>(x, c3, k);
     FHE_SCHED_FENCE();
     Tw7<A> d[2];  // pass 3: one replica ahead
-    tw7_load<A, false, 0>(d[0], t3, k);
+    tw7_load<A, false, R0, 0>(d[0], t3, k);
     STAMP(6);
     xchg_23(x, lane, wl);
     STAMP(7);
@@ -363,11 +382,11 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
     static_for<0, 4>([&](auto abc) {
         constexpr int ab = decltype(abc)::value;
         FHE_SCHED_FENCE();
-        ct_apply<A, P3<0, ab>>(x, d[ab & 1].l0, k);
-        ct_apply<A, P3<1, ab>>(x, d[ab & 1].l1, k);
+        ct_apply<A, P3<R0, 0, ab>>(x, d[ab & 1].l0, k);
+        ct_apply<A, P3<R0, 1, ab>>(x, d[ab & 1].l1, k);
         FHE_SCHED_FENCE();
-        if constexpr (ab < 3) tw7_load<A, false, (ab < 3 ? ab + 1 : 3)>(d[(ab + 1) & 1], t3, k);
-        ct_apply<A, P3<2, ab>>(x, d[ab & 1].l2, k);
+        if constexpr (ab < 3) tw7_load<A, false, R0, (ab < 3 ? ab + 1 : 3)>(d[(ab + 1) & 1], t3, k);
+        ct_apply<A, P3<R0, 2, ab>>(x, d[ab & 1].l2, k);
         FHE_SCHED_FENCE();
         store_p3<A, ab>(x, dst_wave, lane, wl, k);
     });
@@ -382,7 +401,7 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
 
 // One inverse transform; x[] arrives loaded in the pass-3 layout, d[] with the pass-3 twiddles of replicas 0 and 1 (fetched BEFORE
 // the coefficients: vmcnt retires in order, and the twiddles are L2 hits).
-template <class A, bool PFX>
+template <class A, bool PFX, int R0>
 __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
                                         const int t, const int lane, const int w) {
     typedef typename A::TwRaw Tw;
@@ -390,63 +409,69 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     static_for<0, 4>([&](auto abc) {  // pass 3: layers 13, 12, 11; twiddles two replicas ahead (d[] arrives holding replicas 0 and 1)
         constexpr int ab = decltype(abc)::value;
         FHE_SCHED_FENCE();
-        gs_apply<A, P3<2, ab>, 0>(x, d[ab & 1].l2, k);
+        gs_apply<A, P3<R0, 2, ab>, 0>(x, d[ab & 1].l2, k);
         FHE_SCHED_FENCE();
-        gs_apply<A, P3<1, ab>, 1>(x, d[ab & 1].l1, k);
-        gs_apply<A, P3<0, ab>, 2>(x, d[ab & 1].l0, k);
+        gs_apply<A, P3<R0, 1, ab>, 1>(x, d[ab & 1].l1, k);
+        gs_apply<A, P3<R0, 0, ab>, 2>(x, d[ab & 1].l0, k);
         FHE_SCHED_FENCE();
-        if constexpr (ab < 2) tw7_load<A, true, (ab < 2 ? ab + 2 : 3)>(d[ab & 1], t3, k);
+        if constexpr (ab < 2) tw7_load<A, true, R0, (ab < 2 ? ab + 2 : 3)>(d[ab & 1], t3, k);
     });
     FHE_SCHED_FENCE();
     Tw c3[8], c2[4], c1[2], c0[1];
-    tw_load<A, true, P2<3>>(c3, t2, k);
+    tw_load<A, true, P2<R0, 3>>(c3, t2, k);
     xchg_32(x, lane, wl);
     FHE_SCHED_FENCE();
-    tw_load<A, true, P2<2>>(c2, t2, k);
-    gs_apply<A, P2<3>, 3>(x, c3, k);
+    tw_load<A, true, P2<R0, 2>>(c2, t2, k);
+    gs_apply<A, P2<R0, 3>, 3>(x, c3, k);
     FHE_SCHED_FENCE();
-    tw_load<A, true, P2<1>>(c1, t2, k); tw_load<A, true, P2<0>>(c0, t2, k);
-    gs_apply<A, P2<2>, 4>(x, c2, k);
+    tw_load<A, true, P2<R0, 1>>(c1, t2, k); tw_load<A, true, P2<R0, 0>>(c0, t2, k);
+    gs_apply<A, P2<R0, 2>, 4>(x, c2, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P2<1>, 5>(x, c1, k);
+    gs_apply<A, P2<R0, 1>, 5>(x, c1, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P2<0>, 6>(x, c0, k);
+    gs_apply<A, P2<R0, 0>, 6>(x, c0, k);
     FHE_SCHED_FENCE();
     Tw b3[8], b2[4], b1[2], b0[1];  // wave-uniform
-    tw_load<A, true, P1<3>>(b3, w, k); tw_load<A, true, P1<2>>(b2, w, k); tw_load<A, true, P1<1>>(b1, w, k); tw_load<A, true, P1<0>>(b0, w, k);
+    tw_load<A, true, P1<R0, 3>>(b3, w, k); tw_load<A, true, P1<R0, 2>>(b2, w, k); tw_load<A, true, P1<R0, 1>>(b1, w, k); tw_load<A, true, P1<R0, 0>>(b0, w, k);
     xchg_21(x, lane, wl);
     FHE_SCHED_FENCE();
-    gs_apply<A, P1<3>, 7>(x, b3, k);
+    gs_apply<A, P1<R0, 3>, 7>(x, b3, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P1<2>, 8>(x, b2, k);
+    gs_apply<A, P1<R0, 2>, 8>(x, b2, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P1<1>, 9>(x, b1, k);
+    gs_apply<A, P1<R0, 1>, 9>(x, b1, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P1<0>, 10>(x, b0, k);
+    gs_apply<A, P1<R0, 0>, 10>(x, b0, k);
     FHE_SCHED_FENCE();
-    Tw a2[4], a1[2], a0[1];
-    tw_load<A, true, P0<2>>(a2, 0, k); tw_load<A, true, P0<1>>(a1, 0, k);
-    if constexpr (PFX) tw_load<A, true, P0<0>>(a0, 0, k);
-    xchg_10(x, t, w, lds);
+    Tw a3[8], a2[4], a1[2], a0[1];
+    if constexpr (R0 == 4) tw_load<A, true, P0<R0, (R0 == 4 ? 3 : 0)>>(a3, 0, k);
+    tw_load<A, true, P0<R0, 2>>(a2, 0, k); tw_load<A, true, P0<R0, 1>>(a1, 0, k);
+    if constexpr (PFX) tw_load<A, true, P0<R0, 0>>(a0, 0, k);
+    xchg_10<R0>(x, t, w, lds);
+    if constexpr (R0 == 4) {
+        FHE_SCHED_FENCE();
+        gs_apply<A, P0<R0, (R0 == 4 ? 3 : 0)>, 11>(x, a3, k);
+    }
     FHE_SCHED_FENCE();
-    gs_apply<A, P0<2>, 11>(x, a2, k);
+    gs_apply<A, P0<R0, 2>, 8 + R0>(x, a2, k);
     FHE_SCHED_FENCE();
-    gs_apply<A, P0<1>, 12>(x, a1, k);
+    gs_apply<A, P0<R0, 1>, 9 + R0>(x, a1, k);
     // the last layer leaves canonical values: a whole ring folds n^-1 into it (the difference branch multiplies by twi[1] n^-1),
     // a sub-transform of a larger ring is not scaled here at all
     typename A::TwReg wlast{};
     if constexpr (PFX) wlast = A::prep(a0[0]);
-    constexpr int LAST_PH = A::GS_SPAN > 0 ? 13 % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : 1;  // layers since the sums were last folded
-    static_for<0, 4>([&](auto sc) {
-        constexpr int s2 = decltype(sc)::value;
+    constexpr int LAST_PH = A::GS_SPAN > 0 ? (10 + R0) % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : 1;  // layers since the sums were last folded
+    constexpr int HALF = 1 << (R0 - 1), REPS = 32 >> R0;
+    static_for<0, REPS * (HALF / 4)>([&](auto cc) {  // four butterflies at a time, stored as they finish
+        constexpr int pass = decltype(cc)::value / (HALF / 4), j0 = (decltype(cc)::value % (HALF / 4)) * 4;
         FHE_SCHED_FENCE();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = s2 * 8 + j;
-            if constexpr (PFX) A::template gs_last_plain<LAST_PH>(x[o], x[o + 4], wlast, k);
-            else A::template gs_last_scaled<LAST_PH>(x[o], x[o + 4], k);
-            g[(j << 11) | (s2 << 9) | t] = x[o];
-            g[((j + 4) << 11) | (s2 << 9) | t] = x[o + 4];
+        for (int j = j0; j < j0 + 4; ++j) {
+            const int o = (pass << R0) + j;
+            if constexpr (PFX) A::template gs_last_plain<LAST_PH>(x[o], x[o + HALF], wlast, k);
+            else A::template gs_last_scaled<LAST_PH>(x[o], x[o + HALF], k);
+            g[(j << 11) | (pass << (6 + R0)) | t] = x[o];
+            g[((j + HALF) << 11) | (pass << (6 + R0)) | t] = x[o + HALF];
         }
     });
 }
@@ -456,10 +481,11 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
 // One workgroup = one (sub-)polynomial.  (A persistent variant -- two workgroups per CU looping over polynomials, the next one's
 // HBM loads issued behind the last twiddle fetch of the current one -- measured 8-10 % SLOWER at 4096 polynomials than letting
 // the hardware dispatch one-polynomial workgroups: 0.319-0.324 ms against 0.293 ms, tools/ntt_lab2.hip.)
-// PFX = false: whole 2^14 rings (pb = 0).  PFX = true: sub s is sub-transform s & (2^pb - 1) of polynomial s >> pb.
-template <class A, bool PFX>
-__global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
-                                                                       unsigned subs, int pb, NttIo io) {
+// PFX = false: whole rings of 2^(11 + R0) (pb = 0).  PFX = true: sub s is sub-transform s & (2^pb - 1) of polynomial s >> pb.
+template <class A, bool PFX, int R0 = 3>
+__global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                             unsigned n_desc, unsigned subs, int pb, NttIo io) {
+    constexpr int LOG_N = 11 + R0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
@@ -467,18 +493,19 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_fwd_kernel(u64 *__rest
     const unsigned sub = blockIdx.x;
     const unsigned poly = PFX ? sub >> pb : sub;
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
-    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
-    u64 *g = data + (size_t(sub) << 14);
-    const u64 *gs = io.src ? io.src + (size_t(sub % io.src_mod) << 14) : g;
+    const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    u64 *g = data + (size_t(sub) << LOG_N);
+    const u64 *gs = io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g;
     u64 x[32];
-    w14::load_p0<0>(x, gs, t); w14::load_p0<1>(x, gs, t); w14::load_p0<2>(x, gs, t); w14::load_p0<3>(x, gs, t);
-    w14::fwd_one<A>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+    w14::load_p0<R0>(x, gs, t);
+    w14::fwd_one<A, R0>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
 }
 
 // MUL: the launch carries a pointwise multiplier (io.mul), a separate instantiation so that plain transforms do not carry its code
-template <class A, bool PFX, bool MUL = false>
-__global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs, unsigned n_desc,
-                                                                       unsigned subs, int pb, NttIo io) {
+template <class A, bool PFX, bool MUL = false, int R0 = 3>
+__global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
+                                                                             unsigned n_desc, unsigned subs, int pb, NttIo io) {
+    constexpr int LOG_N = 11 + R0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
@@ -486,22 +513,22 @@ __global__ __launch_bounds__(w14::THREADS, 4) void ntt14w_inv_kernel(u64 *__rest
     const unsigned sub = blockIdx.x;
     const unsigned poly = PFX ? sub >> pb : sub;
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
-    const typename A::K k = A::make(D, 14, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
-    u64 *g = data + (size_t(sub) << 14);
+    const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
+    u64 *g = data + (size_t(sub) << LOG_N);
     u64 x[32];
     w14::Tw7<A> d[2];
-    w14::tw7_load<A, true, 0>(d[0], (w << 8) | lane, k);
-    w14::tw7_load<A, true, 1>(d[1], (w << 8) | lane, k);
+    w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
+    w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
     const int off = (w << 11) | (lane << 3);
-    const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << 14) : g) + off;
+    const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g) + off;
     if constexpr (MUL) {
-        const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << 14) + off;
+        const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << LOG_N) + off;
         w14::load_mul_p3<A, 0>(x, src, mul, k); w14::load_mul_p3<A, 1>(x, src, mul, k);
         w14::load_mul_p3<A, 2>(x, src, mul, k); w14::load_mul_p3<A, 3>(x, src, mul, k);
     } else {
         w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
     }
-    w14::inv_one<A, PFX>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+    w14::inv_one<A, PFX, R0>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
 }
 
 }  // namespace fhe

@@ -87,12 +87,12 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // forward 0.280 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.345 against
 // 0.320 -- the inverse's per-lane twiddles are needed first, while the coefficients are still on their way from HBM, and the
 // 16-byte form makes that wait longer than the instructions it saves).
-template <class AF, class AI>
+template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
-    auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true> : fhe::ntt14w_inv_kernel<AI, true, false>) : fhe::ntt14w_fwd_kernel<AF, true>)
-                : (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, false, true> : fhe::ntt14w_inv_kernel<AI, false, false>) : fhe::ntt14w_fwd_kernel<AF, false>);
-    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::LDS_BYTES));
-    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::THREADS), fhe::w14::LDS_BYTES, st, a, d, nd, (unsigned)subs, pb, io);
+    auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
+                : (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, false, true, R0> : fhe::ntt14w_inv_kernel<AI, false, false, R0>) : fhe::ntt14w_fwd_kernel<AF, false, R0>);
+    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>()));
+    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }
@@ -100,6 +100,11 @@ int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, 
 // pm = common bit length of pseudo-Mersenne eligible moduli for which kernels are instantiated (60, 54), else 0
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
+    if (log_n == 15) {  // whole 2^15 rings in one pass over HBM (ntt14w.hpp, R0 = 4): one workgroup of 1024 threads per CU
+        if (pm == 60) return launch14<fhe::ArithDS<60>, fhe::ArithPM<60>, 4>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 54) return launch14<fhe::ArithDS<54>, fhe::ArithPM<54>, 4>(inv, d, nd, a, subs, 0, st, io);
+        return launch14<fhe::ArithShoup, fhe::ArithShoup, 4>(inv, d, nd, a, subs, 0, st, io);
+    }
     if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st, io);
     if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st, io)
                                      : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st, io);
@@ -128,7 +133,7 @@ namespace fhe {
 // io counts POLYNOMIALS; the sub-transform launches take it in 2^14 blocks.
 int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
     if (io.mul) return FHE_ERR_INVALID;  // the pointwise multiplier belongs to the inverse
-    if (log_n <= 14) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st, io);
+    if (log_n <= 15) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st, io);
     const int pb = log_n - 14;
     const size_t cols = batch << 14;
     switch (pb) {  // the opening pass reads the source, everything after it runs in place
@@ -142,7 +147,7 @@ int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size
 }
 
 int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
-    if (log_n <= 14) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st, io);
+    if (log_n <= 15) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st, io);
     const int pb = log_n - 14;
     NttIo sub_io = io;  // polynomial counts -> 2^14 block counts
     sub_io.src_mod = io.src_mod << pb; sub_io.mul_div = io.mul_div << pb; sub_io.mul_period = io.mul_period << pb;
