@@ -277,6 +277,16 @@ int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, c
  * sk1 ignored: the key switches sk0(X^t) back to sk0): rows_a / rows_b [d][n], the layout fhe_ksk_prepare takes. */
 int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n,
                      uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+/* scheme/fhew/src/lwe.rs:128-139 `Lwe::sk_encrypt` for `rows` plaintexts over any modulus q < 2^62 (pt [rows] or NULL = zeros):
+ * out_a [rows][n] uniform, out_b[r] = <a[r], sk> + pt[r] + e[r], e <- dg(3.2, 6). */
+int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, uint64_t seed, uint64_t stream_id,
+                       uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream);
+/* scheme/fhew/src/lwe.rs:108-119 `Lwe::ksk_gen(param, sk0, sk1)`: ksk_a [n1 d][n0], ksk_b [n1 d] (digit-major rows), the layout
+ * fhe_lwe_key_switch / fhe_fhew_bootstrap take with n_in = n1, n_out = n0. */
+int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, uint64_t seed,
+                    uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
+/* util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q, in [count][len] (callers used to loop fhe_rq_add) */
+int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream);
 
 #ifdef __cplusplus
 }

@@ -256,4 +256,72 @@ int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, 
     return rc;
 }
 
+// scheme/fhew/src/lwe.rs:128-139 for `rows` plaintexts (pt [rows] or NULL = zeros): out_a [rows][n] uniform, out_b [rows]
+static int lwe_encrypt_common(uint64_t q, const u64 *sk, const u64 *pt, const u64 *sk1, size_t n1, int rb, int log_b, size_t n, size_t rows,
+                              uint64_t seed, uint64_t stream_id, u64 *out_a, u64 *out_b, hipStream_t st) {
+    fhe::DgTable T;
+    int rc = make_dg_table(3.2, 6, &T);
+    if (rc != FHE_OK) return rc;
+    StreamWs we(rows * sizeof(u64), st);
+    if (we.rc != FHE_OK) return we.rc;
+    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
+    rc = sample_uniform_dev(q, K, 0, out_a, rows * n, st);
+    if (rc == FHE_OK) rc = sample_dg_dev(q, T, K, blocks_uniform(rows * n), we.as<u64>(), rows, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::lwe_encrypt_kernel, dim3(grid_for(rows)), dim3(256), 0, st, (const u64 *)out_a, sk, (const u64 *)we.as<u64>(), pt, out_b, n, rows,
+                           fhe::make_barrett(q), sk1, n1 ? n1 : 1, rb, log_b);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc;
+}
+
+int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, uint64_t seed, uint64_t stream_id,
+                       uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || !sk || n == 0 || ((!out_a || !out_b) && rows)) return FHE_ERR_INVALID;
+    if (rows == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? rows : 0, mem, true, st), ma(out_a, rows * n, mem, false, st), mb(out_b, rows, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    int rc = lwe_encrypt_common(q, msk.d, pt ? mpt.d : nullptr, nullptr, 0, 0, 0, n, rows, seed, stream_id, ma.d, mb.d, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// scheme/fhew/src/lwe.rs:108-119 `Lwe::ksk_gen(param, sk0, sk1)`: rows r = j n1 + i encrypt -sk1[i] base_j under sk0:
+// ksk_a [n1 d][n0], ksk_b [n1 d], the layout fhe_lwe_key_switch takes (n_in = n1, n_out = n0)
+int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, uint64_t seed,
+                    uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+    int rb = 0;
+    int rc = gadget_geometry(q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if ((q >> 62) || !sk0 || !sk1 || n0 == 0 || n1 == 0 || !ksk_a || !ksk_b) return FHE_ERR_INVALID;
+    PtrDeviceGuard pguard(ksk_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = n1 * d;
+    Mirror m0(sk0, n0, mem, true, st), m1(sk1, n1, mem, true, st), ma(ksk_a, rows * n0, mem, false, st), mb(ksk_b, rows, mem, false, st);
+    if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    rc = lwe_encrypt_common(q, m0.d, nullptr, m1.d, n1, rb, log_b, n0, rows, seed, stream_id, ma.d, mb.d, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// util/src/ring.rs:328-341 `Rq: Sum` over `count` polynomials of `len` coefficients: in [count][len] -> out [len]
+int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream) {
+    if (q < 2 || (q >> 62) || ((!in || !out) && len)) return FHE_ERR_INVALID;
+    if (len == 0) return FHE_OK;
+    PtrDeviceGuard pguard(in, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mi(in, len * count, mem, true, st), mo(out, len, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rq_sum_kernel, dim3(grid_for(len)), dim3(256), 0, st, (const u64 *)mi.d, mo.d, len, count, (u64)q);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
 }  // extern "C"

@@ -129,4 +129,35 @@ FHE_HEADER_KERNEL void add_assign_kernel(u64 *__restrict__ out, const u64 *__res
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) out[i] = csub(out[i] + add[i], q);
 }
 
+// scheme/fhew/src/lwe.rs:128-139 `Lwe::sk_encrypt` for `rows` plaintexts: b[r] = <a[r], sk> + pt[r] + e[r] over any modulus q < 2^62
+// (q_ks = 2^16 in the reference's parameter sets).  NEG_POWER_UP: pt[r] = -sk1[r % n1] * base_{r / n1} (lwe.rs:108-119 `ksk_gen`:
+// `power_up(-sk1).flatten()`, digit-major), computed here instead of read.
+FHE_HEADER_KERNEL void lwe_encrypt_kernel(const u64 *__restrict__ a, const u64 *__restrict__ sk, const u64 *__restrict__ e, const u64 *__restrict__ pt,
+                                          u64 *__restrict__ b, size_t n, size_t rows, Barrett B, const u64 *__restrict__ sk1, size_t n1, int rounding_bits,
+                                          int log_b) {
+    for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < rows; r += size_t(gridDim.x) * blockDim.x) {
+        u64 acc = 0;
+        for (size_t j = 0; j < n; ++j) acc = csub(acc + mulmod_barrett(a[r * n + j], sk[j], B), B.q);
+        u64 p;
+        if (sk1) {
+            u64 base = 1 % B.q;
+            for (int s = 0; s < rounding_bits + (int)(r / n1) * log_b; ++s) base = csub(base + base, B.q);
+            const u64 v = sk1[r % n1];
+            p = mulmod_barrett(v ? B.q - v : 0, base, B);
+        } else {
+            p = pt ? pt[r] : 0;
+        }
+        b[r] = csub(csub(acc + p, B.q) + e[r], B.q);
+    }
+}
+
+// util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q over `count` polynomials (any modulus q < 2^62)
+FHE_HEADER_KERNEL void rq_sum_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t len, size_t count, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < len; i += size_t(gridDim.x) * blockDim.x) {
+        u64 acc = 0;
+        for (size_t k = 0; k < count; ++k) acc = csub(acc + in[k * len + i], q);
+        out[i] = acc;
+    }
+}
+
 }  // namespace fhe

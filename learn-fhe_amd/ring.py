@@ -639,3 +639,34 @@ def rlwe_ksk_gen(ctx: NttContext, log_b, d, sk0, sk1, t, n, seed, stream_id):
     pb, _, _, _ = _buf(rb)
     L.check(L.lib().fhe_rlwe_ksk_gen(ctx.handle, log_b, d, p0, p1, t, n, seed, stream_id, pa, pb, mem, st), "fhe_rlwe_ksk_gen")
     return ra, rb
+
+
+def lwe_sk_encrypt(q, sk, pt, n, rows, seed, stream_id):
+    """scheme/fhew/src/lwe.rs:128-139: sk [n], pt [rows] or None -> (a [rows][n], b [rows])."""
+    ps, _, mem, st = _buf(sk)
+    pp = _buf(pt)[0] if pt is not None else None
+    a, b = _like(sk, (rows, n)), _like(sk, (rows,))
+    pa, _, _, _ = _buf(a)
+    pb, _, _, _ = _buf(b)
+    L.check(L.lib().fhe_lwe_sk_encrypt(q, ps, pp, n, rows, seed, stream_id, pa, pb, mem, st), "fhe_lwe_sk_encrypt")
+    return a, b
+
+
+def lwe_ksk_gen(q, log_b, d, sk0, sk1, seed, stream_id):
+    """scheme/fhew/src/lwe.rs:108-119: -> (ksk_a [n1 d][n0], ksk_b [n1 d])."""
+    p0, n0, mem, st = _buf(sk0)
+    p1, n1, _, _ = _buf(sk1)
+    ka, kb = _like(sk0, (n1 * d, n0)), _like(sk0, (n1 * d,))
+    pa, _, _, _ = _buf(ka)
+    pb, _, _, _ = _buf(kb)
+    L.check(L.lib().fhe_lwe_ksk_gen(q, log_b, d, p0, n0, p1, n1, seed, stream_id, pa, pb, mem, st), "fhe_lwe_ksk_gen")
+    return ka, kb
+
+
+def rq_sum(q, a, n):
+    """util/src/ring.rs:328-341 `Rq: Sum`: [count][n] -> [n]."""
+    p, cnt, mem, st = _buf(a)
+    out = _like(a, (n,))
+    po, _, _, _ = _buf(out)
+    L.check(L.lib().fhe_rq_sum(q, p, n, cnt // n, po, mem, st), "fhe_rq_sum")
+    return out

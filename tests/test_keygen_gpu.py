@@ -129,3 +129,73 @@ def test_device_made_keys_decrypt_level(fhe, torch_cuda):
     # host-memory operands take the same path
     ha, hb = fhe.rgsw_encrypt(ctx, log_b, d, host(sk_z), U([m0, m1]), n, 300, 0)
     assert np.array_equal(ha, host(ra).reshape(ha.shape)) and np.array_equal(hb, host(rb).reshape(hb.shape))
+
+
+def test_whole_bootstrapping_key_made_on_the_device(fhe, torch_cuda):
+    """`Bootstrapping::key_gen` (scheme/fhew/src/bootstrapping.rs:122-146) with every key made by the device-side producers -- LWE
+    key-switching key (lwe.rs:108-119), brk = RGSW(X^s_j) (rgsw.rs:84-105), ak = automorphism keys for ak_t (rlwe.rs:122-132), the
+    secret keys themselves from the device's dg(3.2, 6) -- then the reference's own gate test (fhew/boolean.rs:256-290, its
+    `single_key_testing_param`) at decode level, inputs encrypted on the device as well (lwe.rs:128-139)."""
+    from oracle import pyref as P
+    log_q, log_n, log_b, d, w = 28, 9, 7, 4, 10
+    n_lwe, q_ks, kb, kd = 100, 1 << 16, 4, 4
+    n = 1 << log_n
+    q = next(P.two_adic_primes(log_q, log_n + 1))
+    like = dev(torch_cuda, U([0]))
+    ctx = fhe.NttContext(q)
+    z_i = host(fhe.sample_dg(0, 3.2, 6, 900, 0, like, (n,))).view(np.int64)            # ring key z (rlwe.rs:94-96)
+    s_i = host(fhe.sample_dg(0, 3.2, 6, 900, 1, like, (n_lwe,))).view(np.int64)        # LWE key s (lwe.rs:103-106)
+    zq = lambda v, m: dev(torch_cuda, U([int(x) % m for x in v]))  # noqa: E731
+    z_q, z_ks, s_ks = zq(z_i, q), zq(z_i, q_ks), zq(s_i, q_ks)
+    # brk_j = RGSW(X^{s_j}): the monomial plaintexts (bootstrapping.rs:131-136)
+    mono = np.zeros((n_lwe, n), dtype=np.uint64)
+    for j, sj in enumerate(s_i):
+        e = int(sj) % (2 * n)
+        mono[j, e % n] = 1 if e < n else q - 1
+    ra, rb = fhe.rgsw_encrypt(ctx, log_b, d, z_q, dev(torch_cuda, mono), n, 901, 0)
+    ts = P.ak_t(n, w)
+    aks = [fhe.rlwe_ksk_gen(ctx, log_b, d, z_q, None, t, n, 902, i) for i, t in enumerate(ts)]
+    ak_a = torch_cuda.stack([k[0] for k in aks]).contiguous()
+    ak_b = torch_cuda.stack([k[1] for k in aks]).contiguous()
+    ksk_a, ksk_b = fhe.lwe_ksk_gen(q_ks, kb, kd, s_ks, z_ks, 903, 0)                   # Lwe::ksk_gen(lwe_s, &s, z)
+    gk = fhe.GadgetKey(ctx, log_b, d, ra, rb, n, rgsw=True)
+    ga = fhe.GadgetKey(ctx, log_b, d, ak_a, ak_b, n, rgsw=False)
+    bk = fhe.BootstrapKey(ctx, gk, ga, ts, w)
+    ev = fhe.Fhew(bk, q_ks, kb, kd, ksk_a, ksk_b)
+    delta = q / 4.0
+    z = [int(v) for v in z_i]
+    stream = [0]
+
+    def encrypt(bits):
+        stream[0] += 1
+        pt = dev(torch_cuda, U([P.zq_from_f64(q, float(m) * delta) for m in bits]))
+        return fhe.lwe_sk_encrypt(q, z_q, pt, n, len(bits), 904, stream[0])
+
+    def decrypt(ct):
+        a, b = host(ct[0]).reshape(-1, n), host(ct[1])
+        out = []
+        for i in range(a.shape[0]):
+            m = P.zq_from_f64(4, float(P.lwe_decrypt(q, z, L(a[i]), int(b[i]))) / delta)
+            assert m in (0, 1), m
+            out.append(m)
+        return out
+
+    m0 = [(m >> 0) & 1 for m in range(4)]
+    m1 = [(m >> 1) & 1 for m in range(4)]
+    c0, c1 = encrypt(m0), encrypt(m1)
+    assert decrypt(c0) == m0 and decrypt(c1) == m1
+    assert decrypt(ev.nand(c0, c1)) == [1 - (x & y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.and_(c0, c1)) == [x & y for x, y in zip(m0, m1)]
+    assert decrypt(ev.or_(c0, c1)) == [x | y for x, y in zip(m0, m1)]
+    assert decrypt(ev.xor(c0, c1)) == [x ^ y for x, y in zip(m0, m1)]
+    assert decrypt(ev.xor(ev.nand(c0, c1), ev.or_(c0, c1))) == [(1 - (x & y)) ^ (x | y) for x, y in zip(m0, m1)]
+
+
+def test_rq_sum(fhe, torch_cuda):
+    """util/src/ring.rs:328-341 `Rq: Sum`, prime and non-prime moduli, against exact integers"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for q, count, n in [(18014398509404161, 19, 256), (1 << 16, 7, 64), (1152921504606748673, 5, 1024)]:
+        a = rng.integers(0, q, size=(count, n), dtype=np.uint64)
+        exp = [sum(int(a[k, i]) for k in range(count)) % q for i in range(n)]
+        assert L(host(fhe.rq_sum(q, dev(torch_cuda, a), n))) == exp
+        assert L(fhe.rq_sum(q, a, n)) == exp
