@@ -57,6 +57,9 @@ struct ModDesc {
     // w 2^32 mod q = b0 + b1 2^(pm_b-31); ds_pow = 2^(pm_b-31), read from memory so that the compiler keeps the multiply-add
     const uint4 *twd, *twdi;
     unsigned ds_pow;
+    // ... of (2^k)^-1, of (2^k)^-1 twi[1] and of 1: split on the host -- the w 2^32 mod q half is a 128-bit remainder, which a
+    // kernel that formed it itself paid for in every workgroup (0.045 ms of a 0.33 ms launch of 4096 inverse transforms)
+    uint4 ds_ninv[20], ds_ninv_w[20], ds_one;
     // classical Barrett constants (dev_arith.hpp) for products of two VARIABLE operands inside a transform (fused ring products)
     u64 bar_mu;
     int bar_sh1, bar_sh2;
@@ -369,8 +372,8 @@ struct ArithDS {
         k.m.q = D.q; k.m.q2 = 2 * D.q; k.m.q4 = 4 * D.q;
         k.m.c = D.pm_c; k.m.c2 = 2 * D.pm_c; k.m.pw = D.ds_pow;
         k.tw = as_const(D.twd); k.twi = as_const(D.twdi);
-        k.ninv = split(pb ? 1 : D.ninv[log_n_total], D.q);
-        k.ninv_w = split(D.ninv_w[log_n_total], D.q);
+        k.ninv = pb ? D.ds_one : D.ds_ninv[log_n_total];
+        k.ninv_w = D.ds_ninv_w[log_n_total];
         k.pb = pb; k.prefix = prefix;
         return k;
     }
@@ -476,6 +479,11 @@ struct Unit {
     static constexpr int half = 1 << (R_ - 1 - l_);
 };
 
+#ifdef FHE_LAB_ABLATE  // developer lab only (tools/ntt_lab2.hip): a policy may replace the twiddle loads of chosen layers by computed values
+template <class A, class = void> struct tw_skip_mask { static constexpr unsigned value = 0; };
+template <class A> struct tw_skip_mask<A, decltype((void)A::SKIP_MASK)> { static constexpr unsigned value = A::SKIP_MASK; };
+#endif
+
 template <class A, bool INV, class U, int NTW>
 __device__ __forceinline__ void tw_load(typename A::TwRaw (&raw)[NTW], int top, const typename A::K &k) {
     static_assert(U::NT <= NTW, "twiddle buffer too small for this unit");
@@ -485,6 +493,9 @@ __device__ __forceinline__ void tw_load(typename A::TwRaw (&raw)[NTW], int top, 
         for (int b = 0; b < (1 << U::l); ++b) {
             const int tp = U::SHARED ? top : (top | ((U::REP0 + rr) << U::REP_SHIFT));
             const int idx = (1 << (U::L0 + U::l + k.pb)) + ((((k.prefix << U::L0) | tp)) << U::l) + b;
+#ifdef FHE_LAB_ABLATE
+            if constexpr ((tw_skip_mask<A>::value >> (U::L0 + U::l)) & 1) { raw[(rr << U::l) | b] = A::fake(k, idx); continue; }
+#endif
             raw[(rr << U::l) | b] = A::template fetch<INV>(k, idx);
         }
 }

@@ -24,6 +24,7 @@
 // folded into the last layer).  Natural-order coefficients <-> bit-reversed evaluations, twiddle tw[2^layer + block], exactly
 // as the reference.  LDS layouts are conflict free for ds_write_b64 / ds_read_b64 (tools/lds_bank_sim.py).
 #pragma once
+#include <type_traits>
 #include "ntt_kernels.hpp"
 
 namespace fhe {
@@ -62,15 +63,28 @@ __device__ __forceinline__ void wave_sync() {
 #ifdef NTT14_STAMPS
 __device__ unsigned long long g_stamps[4096][16];
 #define STAMP_DECL unsigned long long stamps_[12]
+#define STAMP_ENTRY() unsigned long long entry_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(entry_)::"memory")
+#define STAMP_ENTRY_ARG , entry_
+#define STAMP_ENTRY_PARAM , unsigned long long entry_
 #define STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps_[i])::"memory")
 #define STAMP_REAL(i) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps_[i])::"memory")  /* 100 MHz */
 #define STAMP_FLUSH()                                                                       \
     do {                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < 4096)                                          \
             for (int i_ = 0; i_ < 12; ++i_) g_stamps[blockIdx.x][i_] = stamps_[i_];        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                        \
+            unsigned hw_, xcc_;                                                             \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));               \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));             \
+            g_stamps[blockIdx.x][12] = ((unsigned long long)xcc_ << 32) | hw_;              \
+            g_stamps[blockIdx.x][13] = entry_;                                              \
+        }                                                                                   \
     } while (0)
 #else
 #define STAMP_DECL
+#define STAMP_ENTRY()
+#define STAMP_ENTRY_ARG
+#define STAMP_ENTRY_PARAM
 #define STAMP(i)
 #define STAMP_REAL(i)
 #define STAMP_FLUSH()
@@ -228,6 +242,15 @@ template <int R0, int l> using P1 = Unit<R0, 4, l, 0, 2, 16, true>;
 template <int R0, int l> using P2 = Unit<R0 + 4, 4, l, 0, 2, 16, true>;
 template <int R0, int l, int AB> using P3 = Unit<R0 + 8, 3, l, AB, 1, 8, false, 6>;  // block prefix (w << 8) | (AB << 6) | lane
 
+// pass 3 of the inverse: refill each layer's twiddle slot one replica ahead (true) or fetch whole replicas two ahead (false)
+#ifndef W14_P3_REFILL
+#define W14_P3_REFILL -1
+#endif
+template <class A>
+__device__ __host__ constexpr bool w14_p3_refill() {
+    return W14_P3_REFILL < 0 ? std::is_same<typename A::TwRaw, uint4>::value : W14_P3_REFILL != 0;
+}
+
 // one replica's pass-3 twiddles (layers 11, 12, 13)
 template <class A>
 struct Tw7 {
@@ -309,7 +332,7 @@ __device__ __forceinline__ void store_p3(u64 (&x)[32], u64 *__restrict__ dst_wav
 // One forward transform.  x[] arrives loaded (pass-0 layout, the loads possibly still in flight).
 template <class A, int R0>
 __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
-                                        const int t, const int lane, const int w) {
+                                        const int t, const int lane, const int w STAMP_ENTRY_PARAM) {
     typedef typename A::TwRaw Tw;
     STAMP_DECL;
     STAMP_REAL(10);
@@ -403,23 +426,37 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
 // the coefficients: vmcnt retires in order, and the twiddles are L2 hits).
 template <class A, bool PFX, int R0>
 __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
-                                        const int t, const int lane, const int w) {
+                                        const int t, const int lane, const int w STAMP_ENTRY_PARAM) {
     typedef typename A::TwRaw Tw;
     const int t2 = (w << 4) | (lane >> 2), t3 = (w << 8) | lane;
-    static_for<0, 4>([&](auto abc) {  // pass 3: layers 13, 12, 11; twiddles two replicas ahead (d[] arrives holding replicas 0 and 1)
-        constexpr int ab = decltype(abc)::value;
+    STAMP_DECL;
+    STAMP_REAL(10);
+    STAMP(0);
+    // pass 3: layers 13, 12, 11.  Eight-byte twiddles are fetched two replicas ahead (d[] arrives holding replicas 0 and 1); sixteen-
+    // byte ones (ArithDS) refill each layer's slot for the NEXT replica as soon as the layer has used it -- 28 registers instead
+    // of 56 beside the 64 of x.  The two schemes measure the same (tools/ntt_lab2.hip: 0.331 / 0.333 ms); the refill is kept for the
+    // registers it leaves free.
+    constexpr bool REFILL = w14_p3_refill<A>();
+    Tw c3[8], c2[4], c1[2], c0[1];
+    static_for<0, 4>([&](auto abc) {
+        constexpr int ab = decltype(abc)::value, nx = ab < 3 ? ab + 1 : 3;
+        Tw7<A> &e = d[REFILL ? 0 : ab & 1];
         FHE_SCHED_FENCE();
-        gs_apply<A, P3<R0, 2, ab>, 0>(x, d[ab & 1].l2, k);
+        gs_apply<A, P3<R0, 2, ab>, 0>(x, e.l2, k);
+        if constexpr (REFILL && ab < 3) tw_load<A, true, P3<R0, 2, nx>>(e.l2, t3, k);
         FHE_SCHED_FENCE();
-        gs_apply<A, P3<R0, 1, ab>, 1>(x, d[ab & 1].l1, k);
-        gs_apply<A, P3<R0, 0, ab>, 2>(x, d[ab & 1].l0, k);
+        gs_apply<A, P3<R0, 1, ab>, 1>(x, e.l1, k);
+        if constexpr (REFILL && ab < 3) tw_load<A, true, P3<R0, 1, nx>>(e.l1, t3, k);
+        gs_apply<A, P3<R0, 0, ab>, 2>(x, e.l0, k);
+        if constexpr (REFILL && ab < 3) tw_load<A, true, P3<R0, 0, nx>>(e.l0, t3, k);
         FHE_SCHED_FENCE();
-        if constexpr (ab < 2) tw7_load<A, true, R0, (ab < 2 ? ab + 2 : 3)>(d[ab & 1], t3, k);
+        if constexpr (!REFILL && ab < 2) tw7_load<A, true, R0, (ab < 2 ? ab + 2 : 3)>(d[ab & 1], t3, k);
     });
     FHE_SCHED_FENCE();
-    Tw c3[8], c2[4], c1[2], c0[1];
+    STAMP(1);
     tw_load<A, true, P2<R0, 3>>(c3, t2, k);
     xchg_32(x, lane, wl);
+    STAMP(2);
     FHE_SCHED_FENCE();
     tw_load<A, true, P2<R0, 2>>(c2, t2, k);
     gs_apply<A, P2<R0, 3>, 3>(x, c3, k);
@@ -431,9 +468,11 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     FHE_SCHED_FENCE();
     gs_apply<A, P2<R0, 0>, 6>(x, c0, k);
     FHE_SCHED_FENCE();
+    STAMP(3);
     Tw b3[8], b2[4], b1[2], b0[1];  // wave-uniform
     tw_load<A, true, P1<R0, 3>>(b3, w, k); tw_load<A, true, P1<R0, 2>>(b2, w, k); tw_load<A, true, P1<R0, 1>>(b1, w, k); tw_load<A, true, P1<R0, 0>>(b0, w, k);
     xchg_21(x, lane, wl);
+    STAMP(4);
     FHE_SCHED_FENCE();
     gs_apply<A, P1<R0, 3>, 7>(x, b3, k);
     FHE_SCHED_FENCE();
@@ -443,11 +482,13 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     FHE_SCHED_FENCE();
     gs_apply<A, P1<R0, 0>, 10>(x, b0, k);
     FHE_SCHED_FENCE();
+    STAMP(5);
     Tw a3[8], a2[4], a1[2], a0[1];
     if constexpr (R0 == 4) tw_load<A, true, P0<R0, (R0 == 4 ? 3 : 0)>>(a3, 0, k);
     tw_load<A, true, P0<R0, 2>>(a2, 0, k); tw_load<A, true, P0<R0, 1>>(a1, 0, k);
     if constexpr (PFX) tw_load<A, true, P0<R0, 0>>(a0, 0, k);
     xchg_10<R0>(x, t, w, lds);
+    STAMP(6);
     if constexpr (R0 == 4) {
         FHE_SCHED_FENCE();
         gs_apply<A, P0<R0, (R0 == 4 ? 3 : 0)>, 11>(x, a3, k);
@@ -458,6 +499,7 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     gs_apply<A, P0<R0, 1>, 9 + R0>(x, a1, k);
     // the last layer leaves canonical values: a whole ring folds n^-1 into it (the difference branch multiplies by twi[1] n^-1),
     // a sub-transform of a larger ring is not scaled here at all
+    STAMP(7);
     typename A::TwReg wlast{};
     if constexpr (PFX) wlast = A::prep(a0[0]);
     constexpr int LAST_PH = A::GS_SPAN > 0 ? (10 + R0) % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : 1;  // layers since the sums were last folded
@@ -474,6 +516,13 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
             g[((j + HALF) << 11) | (pass << (6 + R0)) | t] = x[o + HALF];
         }
     });
+    STAMP(8);
+#ifdef NTT14_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(9);
+    STAMP_REAL(11);
+    STAMP_FLUSH();
 }
 
 }  // namespace w14
@@ -485,6 +534,7 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
 template <class A, bool PFX, int R0 = 3>
 __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_fwd_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                              unsigned n_desc, unsigned subs, int pb, NttIo io) {
+    STAMP_ENTRY();
     constexpr int LOG_N = 11 + R0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -498,13 +548,14 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_fwd_kernel(u64 *
     const u64 *gs = io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g;
     u64 x[32];
     w14::load_p0<R0>(x, gs, t);
-    w14::fwd_one<A, R0>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+    w14::fwd_one<A, R0>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w STAMP_ENTRY_ARG);
 }
 
 // MUL: the launch carries a pointwise multiplier (io.mul), a separate instantiation so that plain transforms do not carry its code
 template <class A, bool PFX, bool MUL = false, int R0 = 3>
 __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *__restrict__ data, const ModDesc *__restrict__ descs,
                                                                              unsigned n_desc, unsigned subs, int pb, NttIo io) {
+    STAMP_ENTRY();
     constexpr int LOG_N = 11 + R0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -518,7 +569,7 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     u64 x[32];
     w14::Tw7<A> d[2];
     w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
-    w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
+    if constexpr (!w14::w14_p3_refill<A>()) w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
     const int off = (w << 11) | (lane << 3);
     const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g) + off;
     if constexpr (MUL) {
@@ -528,7 +579,7 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     } else {
         w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
     }
-    w14::inv_one<A, PFX, R0>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w);
+    w14::inv_one<A, PFX, R0>(x, d, g, k, lds, lds + w * w14::WSLOTS, t, lane, w STAMP_ENTRY_ARG);
 }
 
 }  // namespace fhe

@@ -84,9 +84,9 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 
 // N = 2^14 (and the 2^14 sub-transforms of larger rings): the register-resident, wave-local kernels of ntt14w.hpp, two
 // workgroups per CU.  AF / AI: the arithmetic policy of each direction (measured, tools/ntt_lab2.hip, 4096 transforms at 60 bits:
-// forward 0.280 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.345 against
-// 0.320 -- the inverse's per-lane twiddles are needed first, while the coefficients are still on their way from HBM, and the
-// 16-byte form makes that wait longer than the instructions it saves).
+// forward 0.274 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.317 against
+// 0.320 -- a tie: the inverse meets its twiddle-heavy passes first, with the coefficients still on their way from HBM, and there
+// the 16-byte form costs in L2 traffic and registers what it saves in instructions.  The inverse keeps the 8-byte tables.)
 template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
@@ -280,6 +280,8 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
                 return uint4{(unsigned)(w & lo), (unsigned)(w >> (b - 31)), (unsigned)(w1 & lo), (unsigned)(w1 >> (b - 31))};
             };
             for (size_t j = 0; j < cap; ++j) { df[j] = split(c->tw[j]); di[j] = split(c->twi[j]); }
+            for (int k = 0; k < 20; ++k) { c->h_desc.ds_ninv[k] = split(c->ninv[k]); c->h_desc.ds_ninv_w[k] = split(c->ninv_w[k]); }
+            c->h_desc.ds_one = split(1);
             e = hipMalloc((void **)&c->d_twd, 2 * cap * sizeof(uint4));
             c->d_twdi = c->d_twd + cap;
             if (e == hipSuccess) e = hipMemcpy(c->d_twd, df.data(), cap * sizeof(uint4), hipMemcpyHostToDevice);

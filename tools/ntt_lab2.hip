@@ -1,9 +1,12 @@
 // Developer lab: A/B of arithmetic policies and ablations inside the N = 2^14 kernels (ntt14w.hpp), interleaved in one process.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o lab2 tools/ntt_lab2.hip      Run: ./lab2 [batch] [reps]
+#define FHE_LAB_ABLATE 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include "../learn-fhe_amd/csrc/modmath.hpp"
 #include "../learn-fhe_amd/csrc/ntt_kernels.hpp"
 #include "../learn-fhe_amd/csrc/ntt14w.hpp"
@@ -13,6 +16,11 @@ constexpr int N14_THREADS = w14::THREADS;
 constexpr size_t N14_LDS_BYTES = w14::LDS_BYTES;
 struct DSNoTw : ArithDS<60> {  // ablation: butterflies with a computed twiddle, no twiddle loads (wrong results, same work)
     template <bool INV> static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) { return uint4{k.ninv.x + (unsigned)idx, k.ninv.y, k.ninv.z ^ (unsigned)idx, k.ninv.w}; }
+};
+template <unsigned M>
+struct DSSkip : ArithDS<60> {  // ablation: the twiddles of the layers in M are computed, the others loaded
+    static constexpr unsigned SKIP_MASK = M;
+    static __device__ __forceinline__ TwRaw fake(const K &k, int idx) { return uint4{k.ninv.x + (unsigned)idx, k.ninv.y, k.ninv.z ^ (unsigned)idx, k.ninv.w}; }
 };
 struct DSNone : ArithDS<60> {  // ablation: HBM traffic + exchanges only
     static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
@@ -91,6 +99,8 @@ int main(int argc, char **argv) {
         hipMemcpy(ddi, wdi.data(), cap * 16, hipMemcpyHostToDevice);
         hd.tww = dw; hd.twwi = dwi; hd.pm_b = 60; hd.pm_c = (unsigned)((u64(1) << 60) - q);
         hd.twd = dd; hd.twdi = ddi; hd.ds_pow = 1u << (60 - 31);
+        for (int k = 0; k < 20; ++k) { hd.ds_ninv[k] = ArithDS<60>::split(hd.ninv[k], q); hd.ds_ninv_w[k] = ArithDS<60>::split(hd.ninv_w[k], q); }
+        hd.ds_one = ArithDS<60>::split(1, q);
     }
     ModDesc *d_desc;
     hipMalloc(&d_desc, sizeof(ModDesc));
@@ -109,6 +119,11 @@ int main(int argc, char **argv) {
         {"wave-local, DS60", ntt14w_fwd_kernel<ArithDS<60>, false>, ntt14w_inv_kernel<ArithDS<60>, false>, 0, 0, 1},
         {"wave-local, Shoup", ntt14w_fwd_kernel<ArithShoup, false>, ntt14w_inv_kernel<ArithShoup, false>, 0, 0, 1},
         {"wave-local DS60, no twiddle loads", ntt14w_fwd_kernel<DSNoTw, false>, ntt14w_inv_kernel<DSNoTw, false>, 0, 0, 1},
+        {"DS60, pass-3 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x3800>, false>, ntt14w_inv_kernel<DSSkip<0x3800>, false>, 0, 0, 1},
+        {"DS60, pass-2 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x780>, false>, ntt14w_inv_kernel<DSSkip<0x780>, false>, 0, 0, 1},
+        {"DS60, pass-1 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x78>, false>, ntt14w_inv_kernel<DSSkip<0x78>, false>, 0, 0, 1},
+        {"DS60, pass-0 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x7>, false>, ntt14w_inv_kernel<DSSkip<0x7>, false>, 0, 0, 1},
+        {"DS60, pass-0/1 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x7f>, false>, ntt14w_inv_kernel<DSSkip<0x7f>, false>, 0, 0, 1},
         {"wave-local, no butterflies", ntt14w_fwd_kernel<DSNone, false>, ntt14w_inv_kernel<DSNone, false>, 0, 0, 1},
     };
     std::vector<u64> ref(h.size()), got(h.size());
@@ -157,13 +172,16 @@ int main(int argc, char **argv) {
         printf("%-32s fwd %.4f ms %5.0f GB/s (%.3f of 8 TB/s) | inv %.4f ms %5.0f GB/s (%.3f)\n", v.name, v.sf / reps, bytes / (v.sf / reps * 1e-3) / 1e9,
                bytes / (v.sf / reps * 1e-3) / 8e12, v.si / reps, bytes / (v.si / reps * 1e-3) / 1e9, bytes / (v.si / reps * 1e-3) / 8e12);
 #ifdef NTT14_STAMPS
-    for (int vi : {0, 1}) {   // where does a workgroup spend its life?
+    for (int vi : {0, 1, 3})
+    for (int dir : {0, 1}) {   // where does a workgroup spend its life?
         auto &v = vs[vi];
-        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
+        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(dir ? v.i : v.f, dim3(GRID(v)), dim3(N14_THREADS), N14_LDS_BYTES, 0, d, (const ModDesc *)d_desc, 1u, (unsigned)batch, 0, NttIo());
         hipDeviceSynchronize();
         static unsigned long long hs[4096][16];
         hipMemcpyFromSymbol(hs, HIP_SYMBOL(w14::g_stamps), sizeof(hs));
-        const char *names[] = {"issue loads", "pass0 (+load wait)", "xchg01", "pass1", "xchg12", "pass2", "xchg23", "pass3", "canon+store issue"};
+        const char *fnames[] = {"issue loads", "pass0 (+load wait)", "xchg01", "pass1", "xchg12", "pass2", "xchg23", "pass3", "canon+store issue"};
+        const char *inames[] = {"pass3 (+load wait)", "tw issue", "xchg32", "pass2", "xchg21", "pass1", "xchg10", "pass0 l2,l1", "last layer+stores"};
+        const char **names = dir ? inames : fnames;
         double sum[9] = {0}; double life = 0; int cnt = 0;
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int b = 0; b < batch && b < 4096; ++b) {
@@ -173,7 +191,7 @@ int main(int argc, char **argv) {
             if (hs[b][0] < t0) t0 = hs[b][0];
             if (hs[b][9] > t1) t1 = hs[b][9];
         }
-        printf("%s: stamps (s_memtime ticks, avg over %d workgroups; lifetime %.0f; kernel span %llu ticks)\n", v.name, cnt, life / cnt, t1 - t0);
+        printf("%s %s: stamps (s_memtime ticks, avg over %d workgroups; lifetime %.0f; kernel span %llu ticks)\n", v.name, dir ? "INVERSE" : "forward", cnt, life / cnt, t1 - t0);
         for (int p2 = 0; p2 < 9; ++p2) printf("  %-20s %8.0f (%4.1f%%)\n", names[p2], sum[p2] / cnt, 100.0 * sum[p2] / life);
         {
             double ck = 0; int c2 = 0; unsigned long long r0 = ~0ull, r1 = 0;
@@ -182,6 +200,34 @@ int main(int argc, char **argv) {
                 ck += double(hs[b][9] - hs[b][0]) / double(hs[b][11] - hs[b][10]) * 0.1; ++c2;
                 if (hs[b][10] < r0) r0 = hs[b][10];
                 if (hs[b][11] > r1) r1 = hs[b][11];
+            }
+            // per-CU timelines from the 100 MHz stamps: how long does a CU hold 2 / 1 / 0 workgroups between first start and last end?
+            {
+                struct Ev { unsigned long long t; int d; };
+                for (int from_entry : {0, 1}) {
+                std::map<unsigned long long, std::vector<Ev>> cus;
+                double pro = 0;
+                for (int b = 0; b < batch && b < 4096; ++b) {
+                    if (hs[b][11] <= hs[b][10]) continue;
+                    const unsigned hw = (unsigned)hs[b][12], xcc = (unsigned)(hs[b][12] >> 32) & 0xf;
+                    const unsigned long long key = ((unsigned long long)xcc << 16) | (hw & 0xff00);  // cu_id, sh_id, se_id
+                    cus[key].push_back({from_entry ? hs[b][13] : hs[b][10], +1}); cus[key].push_back({hs[b][11], -1});
+                    pro += double(hs[b][10] - hs[b][13]);
+                }
+                double occ[4] = {0}; size_t wgs = 0;
+                for (auto &kv : cus) {
+                    auto &ev = kv.second;
+                    std::sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &b2) { return a.t < b2.t || (a.t == b2.t && a.d < b2.d); });
+                    int lvl = 0; unsigned long long prev = ev.front().t < r0 ? ev.front().t : r0;
+                    for (auto &e : ev) { occ[lvl > 3 ? 3 : lvl] += double(e.t - prev); prev = e.t; lvl += e.d; }
+                    occ[0] += double(r1 - prev);
+                    wgs += ev.size() / 2;
+                }
+                const double tot = double(r1 - r0) * cus.size();
+                printf("  [%s] %zu CUs, %.1f workgroups each; CU time holding 0 / 1 / 2 / 3+ workgroups: %.1f%% / %.1f%% / %.1f%% / %.1f%%; entry -> transform start %.2f us avg\n",
+                       from_entry ? "kernel entry .. stores drained" : "transform start .. stores drained", cus.size(),
+                       double(wgs) / cus.size(), 100 * occ[0] / tot, 100 * occ[1] / tot, 100 * occ[2] / tot, 100 * occ[3] / tot, pro / wgs / 100.0);
+                }
             }
             printf("  in-kernel clock %.3f GHz (s_memtime / s_memrealtime); first start -> last end %.1f us\n", ck / c2, double(r1 - r0) / 100.0);
         }
