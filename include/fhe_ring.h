@@ -207,6 +207,25 @@ void fhe_ckks_key_destroy(fhe_ckks_key *key);
  * ciphertexts: ct_b, ct_a [batch][L][n] over qs, coefficient domain.  n up to 2^17. */
 int fhe_ckks_key_switch(const fhe_rns_ctx *rns, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch,
                         fhe_mem mem, void *stream);
+/* util/src/ring/rns.rs:99-101 `RnsRq::rescale()` = rescale_k(1) over qs alone: drops the last q-limb (the K == 1 branch of
+ * rns.rs:104-111, NOT centred).  in [batch][L][n] -> out [batch][L-1][n]; L >= 2. */
+int fhe_rns_rescale(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream);
+/* scheme/ckks/src/ckks.rs:127-129 `automorphism(t)` of an RnsRq (util/src/avec.rs:34-50 on every limb): in, out [batch][L][n],
+ * in != out.  t is taken mod 2n; CKKS only uses odd t (5^j, -1) and an even t returns FHE_ERR_UNSUPPORTED. */
+int fhe_rns_automorphism(const fhe_rns_ctx *rns, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                         void *stream);
+/* scheme/ckks/src/ckks.rs:274-282 `Ckks::rotate` (key = rtk for j, t = 5^j mod 2n = `param.pow5(j)`) and `Ckks::conjugate`
+ * (key = cjk, t = -1): automorphism of both halves, then the key switch.  ct_b, ct_a [batch][L][n], in place. */
+int fhe_ckks_rotate(const fhe_rns_ctx *rns, const fhe_ckks_key *key, int64_t t, uint64_t *ct_b, uint64_t *ct_a, size_t batch, fhe_mem mem,
+                    void *stream);
+/* scheme/ckks/src/ckks.rs:250-263 `Ckks::mul(param, rlk, ct0, ct1)`: tensor, relinearisation (ckks.rs:265-272) and the closing
+ * `rescale()`.  ct0_*, ct1_* [batch][L][n] over qs, coefficient domain -> out_b, out_a [batch][L-1][n] over qs[0..L-1).
+ * The inputs are transformed once and stay in the evaluation domain through the tensor (7 L transforms + the key switch where
+ * the reference's four `Rq * Rq` take 12 L).  A ciphertext on fewer limbs multiplies through an fhe_rns_ctx over that prefix of
+ * qs (rns.rs:148-158 multiplies on the intersection of the two limb sets). */
+int fhe_ckks_mul(const fhe_rns_ctx *rns, const fhe_ckks_key *rlk, const uint64_t *ct0_b, const uint64_t *ct0_a, const uint64_t *ct1_b,
+                 const uint64_t *ct1_a, uint64_t *out_b, uint64_t *out_a, size_t batch, fhe_mem mem, void *stream);
+
 
 /* ---- TFHE torus path (row T), k = 1 ---------------------------------------------------------------------- */
 /* Torus data are uint64_t values of Z/2^64 (util/src/torus.rs `T64`).  Where the reference multiplies torus polynomials

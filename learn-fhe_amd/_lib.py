@@ -121,6 +121,10 @@ def lib():
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
+        L.fhe_rns_rescale.argtypes = [vp, vp, vp, sz, sz, ci, vp]
+        L.fhe_rns_automorphism.argtypes = [vp, C.c_int64, vp, vp, sz, sz, ci, vp]
+        L.fhe_ckks_rotate.argtypes = [vp, vp, C.c_int64, vp, vp, sz, ci, vp]
+        L.fhe_ckks_mul.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_lwe_sk_encrypt.argtypes = [C.c_uint64, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
         L.fhe_lwe_ksk_gen.argtypes = [C.c_uint64, ci, ci, vp, sz, vp, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
         L.fhe_rq_sum.argtypes = [C.c_uint64, vp, sz, sz, vp, ci, vp]

@@ -19,6 +19,7 @@ struct fhe_rns_ctx {
     void *d_blob = nullptr;            // all conversion tables
     fhe::BaseConv q2p{}, p2q{};
     fhe::RescaleConsts resc{};
+    fhe::RescaleConsts resc_last{};    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
     int max_log_n = 0;                 // largest ring degree every prime supports
     int all_pm = -1;                   // common pseudo-Mersenne bit length of all primes, 0 if none
 };
@@ -151,6 +152,18 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     }
     for (int j = 0; j < K; ++j) half_p[j] = half_of_p(ps[j]);
     const size_t o_hq = bb.put(half_q), o_hp = bb.put(half_p), o_pi = bb.put(pinv), o_pis = bb.put(pinv_s), o_mu = bb.put(red_mu);
+    // rns.rs:99-101 `rescale()`: the same formulas with P = the last q-limb (rns.rs:104-111, the K == 1 branch)
+    std::vector<uint64_t> lhalf_q(L), lhalf_p(1), lpinv(L), lpinv_s(L);
+    if (L >= 2) {
+        const uint64_t pl = qs[L - 1];
+        lhalf_p[0] = pl >> 1;
+        for (int i = 0; i + 1 < L; ++i) {
+            lhalf_q[i] = (pl >> 1) % qs[i];
+            lpinv[i] = fhe::invmod(pl % qs[i], qs[i]);
+            lpinv_s[i] = fhe::shoup(lpinv[i], qs[i]);
+        }
+    }
+    const size_t o_lhq = bb.put(lhalf_q), o_lhp = bb.put(lhalf_p), o_lpi = bb.put(lpinv), o_lpis = bb.put(lpinv_s);
     std::vector<fhe::ModDesc> descs(L + K);
     std::vector<fhe::Barrett> bar(L + K);
     for (int i = 0; i < L + K; ++i) { descs[i] = r->mods[i]->h_desc; bar[i] = r->mods[i]->barrett; }
@@ -170,6 +183,11 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     r->resc.pinv = (const u64 *)base + o_pi; r->resc.pinv_s = (const u64 *)base + o_pis;
     r->resc.red_mu = (const u64 *)base + o_mu;
     r->resc.p2q = r->p2q;
+    r->resc_last = r->resc;  // p2q unused when K == 1
+    r->resc_last.L = L - 1; r->resc_last.K = 1;
+    r->resc_last.p_mod = r->q2p.a_mod + (L - 1);
+    r->resc_last.half_q = (const u64 *)base + o_lhq; r->resc_last.half_p = (const u64 *)base + o_lhp;
+    r->resc_last.pinv = (const u64 *)base + o_lpi; r->resc_last.pinv_s = (const u64 *)base + o_lpis;
     *out = r;
     return FHE_OK;
 }
@@ -318,29 +336,24 @@ int fhe_ckks_ksk_prepare(const fhe_rns_ctx *r, const uint64_t *ksk_b, const uint
     return FHE_OK;
 }
 
-// scheme/ckks/src/ckks.rs:284-293 for `batch` ciphertexts sharing one key: ct_b, ct_a [batch][L][n], in place
-int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch, fhe_mem mem,
-                        void *stream) {
-    if (!r || !key || key->rns != r || ((!ct_b || !ct_a) && batch)) return FHE_ERR_INVALID;
-    if (r->device < 0) return FHE_ERR_NO_DEVICE;
-    if (batch == 0) return FHE_OK;
-    hipStream_t st = (hipStream_t)stream;
-    DeviceGuard guard(r->device);
-    if (!guard.ok) return FHE_ERR_HIP;
+namespace {
+// scheme/ckks/src/ckks.rs:284-293 on device pointers: a_in, add_b (may be null = zero), add_a (may be null), out_b, out_a:
+// [batch][L][n].  out_b = rescale_K(ksk.b * a~) + add_b, out_a = rescale_K(ksk.a * a~) + add_a.  Outputs may alias the addends
+// and a_in (a_in is consumed before anything is written).
+int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_in, const u64 *add_b, const u64 *add_a, u64 *out_b, u64 *out_a,
+                   size_t batch, hipStream_t st) {
     const int log_n = key->log_n;
     const size_t n = size_t(1) << log_n, L = r->L, lk = size_t(r->L + r->K);
-    Mirror mb(ct_b, batch * L * n, mem, true, st), ma(ct_a, batch * L * n, mem, true, st);
-    if (mb.rc | ma.rc) return FHE_ERR_HIP;
     const size_t blk = batch * lk * n;
     StreamWs wsp(3 * blk * sizeof(u64), st);  // ext | pb | pa, each [batch][lk][n]
     if (wsp.rc != FHE_OK) return wsp.rc;
     u64 *ws = wsp.as<u64>();
-    u64 *ext = ws, *pb = ws + blk, *pa = ws + 2 * blk;
+    u64 *ext = ws, *pb = ws + blk;
     int rc = FHE_OK;
     // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps)
-    if (hipMemcpy2DAsync(ext, lk * n * 8, ma.d, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    if (hipMemcpy2DAsync(ext, lk * n * 8, a_in, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK) {
-        launch_extend(ma.d, L * n, ext + L * n, lk * n, n, batch, r->q2p, st);
+        launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
@@ -353,16 +366,150 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
         rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)lk, pb, log_n, 2 * batch * lk, st, r->all_pm, io);
     } else if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::rns_pointwise2_kernel, PointwiseGrid(n, batch * lk).g, dim3(256), 0, st, (const u64 *)ext, (const u64 *)key->d_kb,
-                           (const u64 *)key->d_ka, pb, pa, (unsigned)n, (unsigned)lk, batch * lk, (const fhe::Barrett *)r->d_barrett);
+                           (const u64 *)key->d_ka, pb, pb + blk, (unsigned)n, (unsigned)lk, batch * lk, (const fhe::Barrett *)r->d_barrett);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) {
-        launch_rescale(pb, lk * n, mb.d, L * n, mb.d, L * n, n, batch, r->resc, st);
-        launch_rescale(pa, lk * n, ma.d, L * n, nullptr, 0, n, batch, r->resc, st);
+        launch_rescale(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, st);
+        launch_rescale(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
+    return rc;
+}
+}  // namespace
+
+// scheme/ckks/src/ckks.rs:284-293 for `batch` ciphertexts sharing one key: ct_b, ct_a [batch][L][n], in place
+int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch, fhe_mem mem,
+                        void *stream) {
+    if (!r || !key || key->rns != r || ((!ct_b || !ct_a) && batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << key->log_n, L = r->L;
+    Mirror mb(ct_b, batch * L * n, mem, true, st), ma(ct_a, batch * L * n, mem, true, st);
+    if (mb.rc | ma.rc) return FHE_ERR_HIP;
+    int rc = key_switch_dev(r, key, ma.d, mb.d, nullptr, mb.d, ma.d, batch, st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
+    return rc;
+}
+
+// util/src/ring/rns.rs:99-101 `RnsRq::rescale()` = rescale_k(1): in [batch][L][n] -> out [batch][L-1][n]
+int fhe_rns_rescale(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
+    if (r->L < 2) return FHE_ERR_INVALID;  // the reference would leave an RnsRq without limbs
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t L = r->L;
+    Mirror mi(in, n * batch * L, mem, true, st), mo(out, n * batch * (L - 1), mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    launch_rescale(mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/ckks/src/ckks.rs:127-129 (util/src/avec.rs:34-50 on every limb): in, out [batch][L][n], t odd
+int fhe_rns_automorphism(const fhe_rns_ctx *r, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || !is_pow2(n) || (n >> 30) || ((!in || !out) && batch) || in == out) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    const int64_t two_n = 2 * (int64_t)n;
+    const unsigned tt = (unsigned)(((t % two_n) + two_n) % two_n);  // t.rem_euclid(2n), avec.rs:38
+    if (!(tt & 1) && n > 1) return FHE_ERR_UNSUPPORTED;  // CKKS only ever uses 5^j and -1; an even t is not a permutation
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t L = r->L;
+    Mirror mi(in, n * batch * L, mem, true, st), mo(out, n * batch * L, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::rns_automorphism_kernel, PointwiseGrid(n, batch * L).g, dim3(256), 0, st, (const u64 *)mi.d, mo.d, (unsigned)n, (unsigned)L,
+                       batch * L, tt, (const fhe::Barrett *)r->d_barrett);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/ckks/src/ckks.rs:274-282 `Ckks::rotate` (t = 5^j mod 2N) and `Ckks::conjugate` (t = -1): automorphism, then key switch
+int fhe_ckks_rotate(const fhe_rns_ctx *r, const fhe_ckks_key *key, int64_t t, uint64_t *ct_b, uint64_t *ct_a, size_t batch, fhe_mem mem,
+                    void *stream) {
+    if (!r || !key || key->rns != r || ((!ct_b || !ct_a) && batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    const size_t n = size_t(1) << key->log_n, L = r->L;
+    const int64_t two_n = 2 * (int64_t)n;
+    const unsigned tt = (unsigned)(((t % two_n) + two_n) % two_n);
+    if (!(tt & 1) && n > 1) return FHE_ERR_UNSUPPORTED;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror mb(ct_b, batch * L * n, mem, true, st), ma(ct_a, batch * L * n, mem, true, st);
+    if (mb.rc | ma.rc) return FHE_ERR_HIP;
+    const size_t words = batch * L * n;
+    StreamWs rot(2 * words * sizeof(u64), st);
+    if (rot.rc != FHE_OK) return rot.rc;
+    u64 *rb = rot.as<u64>(), *ra = rb + words;
+    hipLaunchKernelGGL(fhe::rns_automorphism_kernel, PointwiseGrid(n, batch * L).g, dim3(256), 0, st, (const u64 *)mb.d, rb, (unsigned)n, (unsigned)L,
+                       batch * L, tt, (const fhe::Barrett *)r->d_barrett);
+    hipLaunchKernelGGL(fhe::rns_automorphism_kernel, PointwiseGrid(n, batch * L).g, dim3(256), 0, st, (const u64 *)ma.d, ra, (unsigned)n, (unsigned)L,
+                       batch * L, tt, (const fhe::Barrett *)r->d_barrett);
+    HIP_TRY(hipGetLastError());
+    int rc = key_switch_dev(r, key, ra, rb, nullptr, mb.d, ma.d, batch, st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    return rc;
+}
+
+// scheme/ckks/src/ckks.rs:250-263 `Ckks::mul` with the relinearisation key `rlk` (ckks.rs:265-272) and the closing `rescale()`
+// (ckks.rs:123-125): ct0, ct1 [batch][L][n] coefficient domain over qs -> out_b, out_a [batch][L-1][n].  The four input
+// polynomials are transformed once each and stay in the evaluation domain through the tensor:
+// 4 L forward + 3 L inverse transforms where the reference's four `Rq * Rq` take 12 L.
+int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *ct0_b, const uint64_t *ct0_a, const uint64_t *ct1_b,
+                 const uint64_t *ct1_a, uint64_t *out_b, uint64_t *out_a, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || !rlk || rlk->rns != r || ((!ct0_b || !ct0_a || !ct1_b || !ct1_a || !out_b || !out_a) && batch)) return FHE_ERR_INVALID;
+    if (r->L < 2) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int log_n = rlk->log_n;
+    const size_t n = size_t(1) << log_n, L = r->L, words = batch * L * n;
+    if (n >> 31) return FHE_ERR_UNSUPPORTED;
+    const uint64_t *ins[4] = {ct0_b, ct0_a, ct1_b, ct1_a};
+    Mirror m0(ins[0], words, mem, true, st), m1(ins[1], words, mem, true, st), m2(ins[2], words, mem, true, st), m3(ins[3], words, mem, true, st);
+    Mirror mob(out_b, batch * (L - 1) * n, mem, false, st), moa(out_a, batch * (L - 1) * n, mem, false, st);
+    if (m0.rc | m1.rc | m2.rc | m3.rc | mob.rc | moa.rc) return FHE_ERR_HIP;
+    StreamWs wsp(7 * words * sizeof(u64), st);  // e [4][batch][L][n] | d [3][batch][L][n]
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    u64 *e = wsp.as<u64>(), *d = e + 4 * words;
+    const u64 *src[4] = {m0.d, m1.d, m2.d, m3.d};
+    int rc = FHE_OK;
+    for (int i = 0; i < 4 && rc == FHE_OK; ++i) {
+        if (n > 1) {
+            fhe::NttIo io;
+            io.src = src[i]; io.src_mod = (unsigned)(batch * L);
+            rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, e + i * words, log_n, batch * L, st, r->all_pm, io);
+        } else if (hipMemcpyAsync(e + i * words, src[i], words * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::rns_tensor_kernel, PointwiseGrid(n, batch * L).g, dim3(256), 0, st, (const u64 *)e, d, (unsigned)n, (unsigned)L, batch * L,
+                           (const fhe::Barrett *)r->d_barrett);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK && n > 1) rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)L, d, log_n, 3 * batch * L, st, r->all_pm);
+    // (d0, d1) + relinearize(d2) (ckks.rs:262, 265-272): the key switch adds d0 and d1 as it rescales; its outputs reuse e
+    if (rc == FHE_OK) rc = key_switch_dev(r, rlk, d + 2 * words, d, d + words, e, e + words, batch, st);
+    if (rc == FHE_OK) {
+        launch_rescale(e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
+        launch_rescale(e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = mob.sync_out(st);
+    if (rc == FHE_OK) rc = moa.sync_out(st);
     return rc;
 }
 

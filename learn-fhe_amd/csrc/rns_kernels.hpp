@@ -161,4 +161,40 @@ FHE_HEADER_KERNEL void rns_pointwise_kernel(u64 *__restrict__ a, const u64 *__re
     }
 }
 
+// scheme/ckks/src/ckks.rs:256-260, the tensor of `Ckks::mul` in the evaluation domain, limb by limb:
+// d0 = b0 (.) b1, d1 = b0 (.) a1 + a0 (.) b1, d2 = a0 (.) a1.  e: [4][polys][n] in the order b0, a0, b1, a1 (polys = batch * limbs);
+// d: [3][polys][n].  The products of the reference are coefficient-domain `Rq * Rq` (three transforms each): mathematically the
+// same polynomials, so the inverse transforms of d0, d1, d2 are bit-identical to them.
+FHE_HEADER_KERNEL void rns_tensor_kernel(const u64 *__restrict__ e, u64 *__restrict__ d, unsigned n, unsigned limbs, size_t polys,
+                                         const Barrett *__restrict__ B) {
+    const size_t plane = polys * n;
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const unsigned limb = unsigned(y % limbs);
+        const Barrett m{ldc(&B[limb].q, 0), ldc(&B[limb].mu, 0), ldc(&B[limb].sh1, 0), ldc(&B[limb].sh2, 0)};
+        const size_t base = y * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 b0 = e[base + i], a0 = e[plane + base + i], b1 = e[2 * plane + base + i], a1 = e[3 * plane + base + i];
+            d[base + i] = mulmod_barrett(b0, b1, m);
+            d[plane + base + i] = csub(mulmod_barrett(b0, a1, m) + mulmod_barrett(a0, b1, m), m.q);
+            d[2 * plane + base + i] = mulmod_barrett(a0, a1, m);
+        }
+    }
+}
+
+// scheme/ckks/src/ckks.rs:127-129 `CkksCiphertext::automorphism` -> util/src/avec.rs:34-50 on every limb of an RnsRq:
+// in, out [polys][n] (polys = batch * limbs), odd t (a bijection: every output slot is written exactly once)
+FHE_HEADER_KERNEL void rns_automorphism_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, unsigned limbs, size_t polys,
+                                               unsigned t, const Barrett *__restrict__ B) {
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const u64 q = ldc(&B[y % limbs].q, 0);
+        const size_t base = y * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const unsigned it = unsigned((u64(i) * t) & (2 * n - 1));
+            const u64 v = in[base + i];
+            if (it < n) out[base + it] = v;
+            else out[base + it - n] = v ? q - v : 0;
+        }
+    }
+}
+
 }  // namespace fhe

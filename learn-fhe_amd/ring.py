@@ -380,6 +380,25 @@ class RnsContext:
         return out
 
 
+    def rescale(self, limbs, n):
+        """rns.rs:99-101 `rescale()`: [batch][L][n] -> [batch][L-1][n]."""
+        p, cnt, mem, st = _buf(limbs)
+        batch = cnt // (self.L * n)
+        out = _like(limbs, (batch, self.L - 1, n))
+        po, _, _, _ = _buf(out)
+        L.check(L.lib().fhe_rns_rescale(self._h, p, po, n, batch, mem, st), "fhe_rns_rescale")
+        return out
+
+    def automorphism(self, limbs, t, n):
+        """ckks.rs:127-129 on [batch][L][n]."""
+        p, cnt, mem, st = _buf(limbs)
+        batch = cnt // (self.L * n)
+        out = _like(limbs, (batch, self.L, n))
+        po, _, _, _ = _buf(out)
+        L.check(L.lib().fhe_rns_automorphism(self._h, t, p, po, n, batch, mem, st), "fhe_rns_automorphism")
+        return out
+
+
 class CkksKey:
     """A CKKS key-switching key (scheme/ckks/src/ckks.rs:86-88) prepared in the evaluation domain."""
 
@@ -402,6 +421,22 @@ class CkksKey:
         pa, _, _, _ = _buf(ct_a)
         batch = cnt // (self.rns.L * self.n)
         L.check(L.lib().fhe_ckks_key_switch(self.rns.handle, self._h, pb, pa, batch, mem, st), "fhe_ckks_key_switch")
+
+    def rotate_(self, t, ct_b, ct_a):
+        """scheme/ckks/src/ckks.rs:274-282 (rotate: t = 5^j mod 2n; conjugate: t = -1), in place."""
+        pb, cnt, mem, st = _buf(ct_b)
+        pa, _, _, _ = _buf(ct_a)
+        batch = cnt // (self.rns.L * self.n)
+        L.check(L.lib().fhe_ckks_rotate(self.rns.handle, self._h, t, pb, pa, batch, mem, st), "fhe_ckks_rotate")
+
+    def mul(self, ct0_b, ct0_a, ct1_b, ct1_a):
+        """scheme/ckks/src/ckks.rs:250-263 with this key as the relinearisation key -> (b, a) on L-1 limbs."""
+        p0b, cnt, mem, st = _buf(ct0_b)
+        p0a, p1b, p1a = _buf(ct0_a)[0], _buf(ct1_b)[0], _buf(ct1_a)[0]
+        batch = cnt // (self.rns.L * self.n)
+        ob, oa = _like(ct0_b, (batch, self.rns.L - 1, self.n)), _like(ct0_b, (batch, self.rns.L - 1, self.n))
+        L.check(L.lib().fhe_ckks_mul(self.rns.handle, self._h, p0b, p0a, p1b, p1a, _buf(ob)[0], _buf(oa)[0], batch, mem, st), "fhe_ckks_mul")
+        return ob, oa
 
 
 # ---- row T: TFHE torus path ------------------------------------------------------------------------------

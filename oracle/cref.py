@@ -229,6 +229,40 @@ def ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a):
     return ct_b, ct_a
 
 
+def rns_mul(qs, a, b):
+    """util/src/ring/rns.rs:148-158 on coefficient-domain limbs: [L][n] x [L][n]"""
+    a, b = _arr(a).copy(), _arr(b)
+    for i, q in enumerate(qs):
+        a[i] = ntt_mul(q, a[i], b[i], a.shape[-1])
+    return a
+
+
+def rns_automorphism(qs, limbs, t):
+    limbs = _arr(limbs)
+    return np.stack([automorphism(q, t, limbs[i]) for i, q in enumerate(qs)])
+
+
+def _rns_add(qs, a, b):
+    qv = np.array(qs, dtype=np.uint64)[:, None]
+    s = a + b  # < 2^63 for the 62-bit moduli of this code base
+    return np.where(s >= qv, s - qv, s)
+
+
+def ckks_rotate(qs, ps, key_b, key_a, t, ct_b, ct_a):
+    """scheme/ckks/src/ckks.rs:274-282"""
+    return ckks_key_switch(qs, ps, key_b, key_a, rns_automorphism(qs, ct_b, t), rns_automorphism(qs, ct_a, t))
+
+
+def ckks_mul(qs, ps, rlk_b, rlk_a, ct0_b, ct0_a, ct1_b, ct1_a):
+    """scheme/ckks/src/ckks.rs:250-272 composed from the C primitives"""
+    ct0_b, ct0_a, ct1_b, ct1_a = _arr(ct0_b), _arr(ct0_a), _arr(ct1_b), _arr(ct1_a)
+    d0 = rns_mul(qs, ct0_b, ct1_b)
+    d1 = _rns_add(qs, rns_mul(qs, ct0_b, ct1_a), rns_mul(qs, ct0_a, ct1_b))
+    d2 = rns_mul(qs, ct0_a, ct1_a)
+    kb, ka = ckks_key_switch(qs, ps, rlk_b, rlk_a, np.zeros_like(d2), d2)
+    return rns_rescale_k(qs, 1, _rns_add(qs, d0, kb)), rns_rescale_k(qs, 1, _rns_add(qs, d1, ka))
+
+
 def num_threads():
     return lib().ref_num_threads()
 

@@ -745,6 +745,27 @@ def ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b, ct_a):
     return b, a
 
 
+def rns_automorphism(qs, limbs, t):
+    """scheme/ckks/src/ckks.rs:127-129: util/src/avec.rs:34-50 on every limb."""
+    return [automorphism(q, l, t) for q, l in zip(qs, limbs)]
+
+
+def ckks_rotate(qs, ps, key_b, key_a, t, ct_b, ct_a):
+    """scheme/ckks/src/ckks.rs:274-282 (`rotate`: t = pow5(j); `conjugate`: t = -1)."""
+    return ckks_key_switch(qs, ps, key_b, key_a, rns_automorphism(qs, ct_b, t), rns_automorphism(qs, ct_a, t))
+
+
+def ckks_mul(qs, ps, rlk_b, rlk_a, ct0_b, ct0_a, ct1_b, ct1_a):
+    """scheme/ckks/src/ckks.rs:250-272: tensor, relinearize(d2) = key_switch(rlk, (0, d2)), sum, rescale()."""
+    n = len(ct0_b[0])
+    add = lambda x, y: [poly_add(q, u, v) for q, u, v in zip(qs, x, y)]  # noqa: E731
+    d0 = rns_mul(qs, ct0_b, ct1_b)
+    d1 = add(rns_mul(qs, ct0_b, ct1_a), rns_mul(qs, ct0_a, ct1_b))
+    d2 = rns_mul(qs, ct0_a, ct1_a)
+    kb, ka = ckks_key_switch(qs, ps, rlk_b, rlk_a, [[0] * n for _ in qs], d2)
+    return rns_rescale_k(qs, add(d0, kb), 1), rns_rescale_k(qs, add(d1, ka), 1)
+
+
 def ckks_primes(log_n, log_qi, big_l):
     """scheme/ckks/src/ckks.rs:20-35."""
     gen = two_adic_primes(log_qi, log_n + 1)

@@ -261,3 +261,25 @@ def test_lwe_golden():
     xa, xb = R.lwe_key_switch(q, 4, 4, np.array(ka, dtype=np.uint64), kb, a, b)
     assert L(xa) == oa and xb == ob
     assert abs(P.zq_to_i64(q, (P.lwe_decrypt(q, s0, oa, ob) - 12345) % q)) < 2048
+
+
+def test_ckks_mul_rotate_c_vs_python():
+    """the two oracles agree on `Ckks::mul` / `rotate` (scheme/ckks/src/ckks.rs:250-282)"""
+    import numpy as np
+    from oracle import cref, pyref as P
+    log_n, bits, big_l, big_k = 4, 50, 3, 2
+    n = 1 << log_n
+    primes = cref.two_adic_primes(bits, log_n + 1, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rng = np.random.Generator(np.random.PCG64(5))
+    limbs = lambda mods: np.stack([rng.integers(0, m, size=n, dtype=np.uint64) for m in mods])  # noqa: E731
+    kb, ka = limbs(qs + ps), limbs(qs + ps)
+    cts = [limbs(qs) for _ in range(4)]
+    ints = lambda a: [[int(v) for v in row] for row in a]  # noqa: E731
+    eb, ea = cref.ckks_mul(qs, ps, kb, ka, *cts)
+    pb, pa = P.ckks_mul(qs, ps, ints(kb), ints(ka), *[ints(c) for c in cts])
+    assert ints(eb) == pb and ints(ea) == pa
+    for t in (25, -1):
+        eb, ea = cref.ckks_rotate(qs, ps, kb, ka, t, cts[0], cts[1])
+        pb, pa = P.ckks_rotate(qs, ps, ints(kb), ints(ka), t, ints(cts[0]), ints(cts[1]))
+        assert ints(eb) == pb and ints(ea) == pa, t

@@ -210,3 +210,147 @@ def test_ckks_key_switch_limb_sharded(tmp_path, world, log_n):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == world
+
+
+# ---- homomorphic CKKS operations on top of the key switch ----------------------------------
+
+@pytest.mark.parametrize("log_n,bits,big_l,big_k", [(4, 50, 3, 3), (10, 55, 4, 2), (13, 60, 2, 2), (14, 60, 3, 1)])
+def test_ckks_mul_vs_oracle(fhe, cref, torch_cuda, log_n, bits, big_l, big_k):
+    """`Ckks::mul` (scheme/ckks/src/ckks.rs:250-272) on random limbs, all 2 x (L-1) output limbs bit-exact"""
+    n, batch = 1 << log_n, 3
+    primes = cref.two_adic_primes(bits, log_n + 1, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(21, qs + ps, n), rand_limbs(22, qs + ps, n)
+    cts = [rand_limbs(23 + i, qs, n, batch) for i in range(4)]
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    ob, oa = key.mul(*[dev(torch_cuda, c) for c in cts])
+    assert tuple(ob.shape) == (batch, big_l - 1, n)
+    for i in range(batch):
+        eb, ea = cref.ckks_mul(qs, ps, kb, ka, *[c[i] for c in cts])
+        assert np.array_equal(host(ob)[i], eb) and np.array_equal(host(oa)[i], ea), i
+    # host-memory call: same result
+    hb, ha = key.mul(*cts)
+    assert np.array_equal(hb, host(ob)) and np.array_equal(ha, host(oa))
+
+
+def test_ckks_mul_cfg4_shape(fhe, cref, torch_cuda):
+    """the BASELINE cfg4 parameter set (N = 2^15, 8 + 8 sixty-bit primes): one `Ckks::mul`, all 2 x 7 output limbs"""
+    g = load_golden("moduli.json")
+    qs, ps = g["cfg4_qs"], g["cfg4_ps"]
+    n = 1 << 15
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(31, qs + ps, n), rand_limbs(32, qs + ps, n)
+    cts = [rand_limbs(33 + i, qs, n, 1) for i in range(4)]
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    ob, oa = key.mul(*[dev(torch_cuda, c) for c in cts])
+    eb, ea = cref.ckks_mul(qs, ps, kb, ka, *[c[0] for c in cts])
+    assert np.array_equal(host(ob)[0], eb) and np.array_equal(host(oa)[0], ea)
+
+
+@pytest.mark.parametrize("log_n,bits,big_l,big_k", [(4, 50, 3, 3), (11, 55, 4, 4), (15, 60, 2, 2)])
+def test_ckks_rotate_conjugate_rescale_vs_oracle(fhe, cref, torch_cuda, log_n, bits, big_l, big_k):
+    """`Ckks::rotate` / `conjugate` (ckks.rs:274-282), `RnsRq::automorphism` and `rescale()` (rns.rs:99-111)"""
+    n, batch = 1 << log_n, 2
+    primes = cref.two_adic_primes(bits, log_n + 1, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(41, qs + ps, n), rand_limbs(42, qs + ps, n)
+    cb, ca = rand_limbs(43, qs, n, batch), rand_limbs(44, qs, n, batch)
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    for t in (pow(5, 3, 2 * n), -1, 2 * n + 5):
+        b, a = dev(torch_cuda, cb), dev(torch_cuda, ca)
+        key.rotate_(t, b, a)
+        for i in range(batch):
+            eb, ea = cref.ckks_rotate(qs, ps, kb, ka, t, cb[i], ca[i])
+            assert np.array_equal(host(b)[i], eb) and np.array_equal(host(a)[i], ea), (t, i)
+        au = rns.automorphism(dev(torch_cuda, cb), t, n)
+        for i in range(batch):
+            assert np.array_equal(host(au)[i], cref.rns_automorphism(qs, cb[i], t)), (t, i)
+    out = rns.rescale(dev(torch_cuda, cb), n)
+    for i in range(batch):
+        assert np.array_equal(host(out)[i], cref.rns_rescale_k(qs, 1, cb[i])), i
+    with pytest.raises(fhe.FheError):
+        rns.automorphism(dev(torch_cuda, cb), 4, n)  # even t: not a permutation, refused
+
+
+def test_ckks_mul_rotate_decrypt(fhe, torch_cuda):
+    """Decrypt level, as the reference's own `mul` / `rotate` / `conjugate` tests (scheme/ckks/src/ckks.rs:378-420) minus the
+    encoder: keys and ciphertexts made with the Python oracle (ckks.rs:139-161, 215-225), the products on the device;
+    b' + a' s must be round(pt0 pt1 / q_last) resp. pt(X^t) up to the scheme's noise."""
+    from oracle import pyref as P
+    log_n, bits, big_l = 5, 50, 3
+    n = 1 << log_n
+    primes = list(P.ckks_primes(log_n, bits, big_l)) if False else None
+    allp = []
+    it = P.two_adic_primes(bits, log_n + 1)
+    while len(allp) < 2 * big_l:
+        allp.append(next(it))
+    qs, ps = allp[:big_l], allp[big_l:]
+    qps = qs + ps
+    rnd = random.Random(77)
+    big_p = math.prod(ps)
+    sk = [rnd.choice([-1, 0, 0, 1]) for _ in range(n)]  # zo(0.5), ckks.rs:139-141
+    lift = lambda mods, v: [[x % m for x in v] for m in mods]  # noqa: E731
+    small = lambda: [rnd.randint(-6, 6) for _ in range(n)]  # noqa: E731
+
+    def negacyclic(a, b):
+        c = [0] * n
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                if i + j < n:
+                    c[i + j] += x * y
+                else:
+                    c[i + j - n] -= x * y
+        return c
+
+    def encrypt(mods, pt_big):  # ckks.rs:215-225: b = -(a s) + e + pt
+        a = [[rnd.randrange(m) for _ in range(n)] for m in mods]
+        e = small()
+        a_s = P.rns_mul(mods, a, lift(mods, sk))
+        b = [[(-x + ee + p) % m for x, ee, p in zip(row, e, pt_big)] for m, row in zip(mods, a_s)]
+        return b, a
+
+    def decrypt(mods, b, a):  # ckks.rs:241-248, then the centred integer by CRT
+        a_s = P.rns_mul(mods, a, lift(mods, sk))
+        pt = [[(x + y) % m for x, y in zip(rb, ra)] for m, rb, ra in zip(mods, b, a_s)]
+        big_q = math.prod(mods)
+        out = []
+        for i in range(n):
+            v = 0
+            for m, row in zip(mods, pt):
+                qh = big_q // m
+                v += row[i] * qh * pow(qh, -1, m)
+            v %= big_q
+            out.append(v - big_q if v > big_q // 2 else v)
+        return out
+
+    def ksk_gen(sk_prime):  # ckks.rs:154-161: pt = sk' * P over qs ++ ps
+        return encrypt(qps, [x * big_p for x in sk_prime])
+
+    U = lambda rows: np.array(rows, dtype=np.uint64)  # noqa: E731
+    rns = fhe.RnsContext(qs, ps)
+    delta = 1 << 45
+    m0, m1 = small(), small()
+    ct0, ct1 = encrypt(qs, [delta * x for x in m0]), encrypt(qs, [delta * x for x in m1])
+    assert max(abs(x - delta * y) for x, y in zip(decrypt(qs, *ct0), m0)) < 64
+    # mul with rlk = ksk_gen(sk, sk^2) (ckks.rs:163-166)
+    rlk = ksk_gen(negacyclic(sk, sk))
+    key = fhe.CkksKey(rns, dev(torch_cuda, U(rlk[0])), dev(torch_cuda, U(rlk[1])), n)
+    ob, oa = key.mul(*[dev(torch_cuda, U(x)[None]) for x in (ct0[0], ct0[1], ct1[0], ct1[1])])
+    got = decrypt(qs[:-1], [L_(r) for r in host(ob)[0]], [L_(r) for r in host(oa)[0]])
+    want = negacyclic(m0, m1)
+    scale2 = delta * delta / qs[-1]
+    err = max(abs(g - scale2 * w) for g, w in zip(got, want))
+    assert err < 2 ** 16, err  # noise: e m Delta / q_last + key-switch noise + rounding, far below Delta^2 / q_last = 2^40
+    # rotate / conjugate with rtk = ksk_gen(sk, sk(X^t)) (ckks.rs:168-183)
+    for t in (pow(5, 2, 2 * n), -1):
+        sk_t = [x - qs[0] if x > qs[0] // 2 else x for x in P.automorphism(qs[0], [x % qs[0] for x in sk], t)]
+        rtk = ksk_gen(sk_t)
+        kt = fhe.CkksKey(rns, dev(torch_cuda, U(rtk[0])), dev(torch_cuda, U(rtk[1])), n)
+        b, a = dev(torch_cuda, U(ct0[0])[None]), dev(torch_cuda, U(ct0[1])[None])
+        kt.rotate_(t, b, a)
+        got = decrypt(qs, [L_(r) for r in host(b)[0]], [L_(r) for r in host(a)[0]])
+        big = 1 << 62
+        want = [x - big if x > big // 2 else x for x in P.automorphism(big, [(delta * x) % big for x in m0], t)]
+        assert max(abs(g - w) for g, w in zip(got, want)) < 2 ** 16, t
