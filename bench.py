@@ -139,12 +139,12 @@ def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
     out["external_products_per_sec_batch4096"] = 4096 / dt
     ep_bytes = (4 * d + 4) * 8 * n                      # ct in + 2d rows x (a, b) + ct out
     ks_bytes = (2 * d + 4) * 8 * n
-    out["roofline_external_product"] = roof(4096 / dt, ep_bytes, "external_product_kernel<WaveRing<10>, ArithPM<54>> (fused decompose -> NTT -> accumulate)",
+    out["roofline_external_product"] = roof(4096 / dt, ep_bytes, "gadget_product_kernel<ArithDS<54>, WaveRing<10, 3>> (fused decompose -> NTT -> accumulate)",
                                             "key rows (288 KiB per RGSW ciphertext) are L2 / Infinity-Cache hits: the kernel is bound by VALU issue, not HBM")
     if n_auto is not None:
         br_bytes = n_lwe * ep_bytes + n_auto * ks_bytes
         out["automorphism_key_switches_per_blind_rotation"] = n_auto
-        out["roofline"] = roof(out["blind_rotations_per_sec_batch1024"], br_bytes, "blind_rotate_kernel<WaveRing<10>, ArithPM<54>> (batch 1024)",
+        out["roofline"] = roof(out["blind_rotations_per_sec_batch1024"], br_bytes, "blind_rotate_kernel<ArithDS<54>, WaveRing<10, 3>> (batch 1024)",
                                "%d external products x %d B + %.1f automorphism key switches x %d B per blind rotation; keys cache resident"
                                % (n_lwe, ep_bytes, n_auto, ks_bytes))
     return out
@@ -169,6 +169,12 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
         cb, ca = limbs(qs, b), limbs(qs, b)
         dt = _timeit(torch, lambda: key.key_switch_(cb, ca), reps)
         out["key_switches_per_sec_batch%d" % b] = b / dt
+    # `Ckks::mul` (ckks.rs:250-263: tensor + relinearisation + rescale) on the same parameter set, 7 L transforms + one key switch
+    b = 2 * batch
+    c4 = [limbs(qs, b) for _ in range(4)]
+    dt = _timeit(torch, lambda: key.mul(*c4), reps)
+    out["muls_per_sec_batch%d" % b] = b / dt
+    del c4
     # ct in 2L 8N + ksk 2(L+K) 8N + ct out 2L 8N = 16 MiB at cfg4
     out["roofline"] = roof(out["key_switches_per_sec_batch%d" % (8 * batch)], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
                            "rns_extend + ntt14w_fwd<R0=4> + ntt14w_inv<R0=4> (2^15 rings in one pass; ksk products fused into the inverse's load) + rns_rescale x2",

@@ -306,6 +306,27 @@ int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0
                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
 /* util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q, in [count][len] (callers used to loop fhe_rq_add) */
 int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream);
+/* ---- TFHE key material, k = 1.  Draws are counter based (ChaCha20, as above): reproducible per
+ * (seed, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
+/* util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: torus Gaussian noise (Box-Muller deviate, fractional part scaled by 2^64) */
+int fhe_sample_tdg(double std_dev, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+/* distribution.rs `binary()` (scheme/tfhe/src/tlwe.rs:96-98 `Tlwe::sk_gen`): one uniform bit per output word */
+int fhe_sample_binary(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tlwe.rs:122-132 `Tlwe::sk_encrypt` for `rows` plaintexts (pt [rows] or NULL): out_a [rows][n], out_b [rows] */
+int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed, uint64_t stream_id,
+                        uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tlwe.rs:100-111 `Tlwe::ksk_gen(param, sk0, sk1)`: ksk_a [n1 d][n0], ksk_b [n1 d] (digit-major), the layout
+ * fhe_tlwe_key_switch / fhe_tfhe_bootstrap take with n_in = n1, n_out = n0 */
+int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, uint64_t seed,
+                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tglwe.rs:91-103 `Tglwe::sk_encrypt`: ct_a uniform, ct_b = ct_a * sk + e + pt, [rows][n]; sk [n] binary; pt NULL = zeros.
+ * The product a * sk is the exact integer product of row T. */
+int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed,
+                         uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tggsw.rs:73-88 `Tggsw::sk_encrypt` for `count` plaintext polynomials pt [count][n] (bootstrapping.rs:64-69: the
+ * constants z_i): rows_a, rows_b [count][2d][n], the layout fhe_tggsw_prepare takes */
+int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, double std_dev,
+                      uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
 
 #ifdef __cplusplus
 }

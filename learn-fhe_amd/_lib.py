@@ -121,6 +121,13 @@ def lib():
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
+        u64, dbl = C.c_uint64, C.c_double
+        L.fhe_sample_tdg.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
+        L.fhe_sample_binary.argtypes = [u64, u64, vp, sz, ci, vp]
+        L.fhe_tlwe_sk_encrypt.argtypes = [vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
+        L.fhe_tlwe_ksk_gen.argtypes = [ci, ci, vp, sz, vp, sz, dbl, u64, u64, vp, vp, ci, vp]
+        L.fhe_tglwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
+        L.fhe_tggsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
         L.fhe_rns_rescale.argtypes = [vp, vp, vp, sz, sz, ci, vp]
         L.fhe_rns_automorphism.argtypes = [vp, C.c_int64, vp, vp, sz, sz, ci, vp]
         L.fhe_ckks_rotate.argtypes = [vp, vp, C.c_int64, vp, vp, sz, ci, vp]

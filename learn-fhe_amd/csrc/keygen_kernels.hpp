@@ -129,6 +129,66 @@ FHE_HEADER_KERNEL void add_assign_kernel(u64 *__restrict__ out, const u64 *__res
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) out[i] = csub(out[i] + add[i], q);
 }
 
+// util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: v ~ N(0, std_dev), frac = v - round(v), T64 = round(frac 2^64) as i64
+// (Rust's float -> int cast saturates).  The normal deviate is Box-Muller on two words of the generator: the reference's
+// `rand_distr::Normal` is a different sampler of the same distribution, and its draws are unseeded.
+FHE_HEADER_KERNEL void sample_tdg_kernel(u64 *__restrict__ out, size_t count, double std_dev, ChaChaKey K, unsigned long long first) {
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 4 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = blk * 4 + j;
+            if (i >= count) continue;
+            const double u1 = (double)((w[2 * j] >> 11) + 1) * (1.0 / 9007199254740992.0);  // (0, 1]
+            const double u2 = (double)(w[2 * j + 1] >> 11) * (1.0 / 9007199254740992.0);    // [0, 1)
+            const double v = std_dev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+            const double x = round((v - round(v)) * 18446744073709551616.0);
+            const long long r = x >= 9223372036854775807.0 ? 0x7fffffffffffffffll : (x <= -9223372036854775808.0 ? (long long)0x8000000000000000ull : (long long)x);
+            out[i] = (u64)r;
+        }
+    }
+}
+// util/src/misc/distribution.rs `binary()`: uniform bits, one per output word (scheme/tfhe/src/tlwe.rs:96-98 `sk_gen`)
+FHE_HEADER_KERNEL void sample_binary_kernel(u64 *__restrict__ out, size_t count, ChaChaKey K, unsigned long long first) {
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 512 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+        for (int j = 0; j < 512; ++j)
+            if (blk * 512 + j < count) out[blk * 512 + j] = (w[j >> 6] >> (j & 63)) & 1;
+    }
+}
+
+// scheme/tfhe/src/tlwe.rs:122-132 `Tlwe::sk_encrypt` for `rows` plaintexts on the torus (wrapping u64): b[r] = <a[r], sk> + e[r] + pt[r].
+// sk1 != null: pt[r] = -sk1[r % n1] * 2^(rounding_bits + (r / n1) log_b) (tlwe.rs:100-111 `ksk_gen`: `power_up(-sk1).flatten()`)
+FHE_HEADER_KERNEL void tlwe_encrypt_kernel(const u64 *__restrict__ a, const u64 *__restrict__ sk, const u64 *__restrict__ e, const u64 *__restrict__ pt,
+                                           u64 *__restrict__ b, size_t n, size_t rows, const u64 *__restrict__ sk1, size_t n1, int rounding_bits, int log_b) {
+    for (size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x; r < rows; r += size_t(gridDim.x) * blockDim.x) {
+        u64 acc = 0;
+        for (size_t j = 0; j < n; ++j) acc += a[r * n + j] * sk[j];
+        u64 p;
+        if (sk1) p = (0 - sk1[r % n1]) << (rounding_bits + (int)(r / n1) * log_b);
+        else p = pt ? pt[r] : 0;
+        b[r] = acc + e[r] + p;
+    }
+}
+// torus polynomials: b <- b + e + pt (tglwe.rs:101), pt [pt_rows][n] cycled or null
+FHE_HEADER_KERNEL void torus_add3_kernel(u64 *__restrict__ b, const u64 *__restrict__ e, const u64 *__restrict__ pt, size_t count, size_t pt_mod) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x)
+        b[i] += e[i] + (pt ? pt[i % pt_mod] : 0);
+}
+// scheme/tfhe/src/tggsw.rs:80-87 (k = 1): rows [count][2d][n]; row j < d: a += pt 2^(rb + j log_b); row d + j: b += the same
+FHE_HEADER_KERNEL void tggsw_add_gadget_kernel(u64 *__restrict__ rows_a, u64 *__restrict__ rows_b, const u64 *__restrict__ pt, size_t n, size_t count, int d,
+                                               int rounding_bits, int log_b) {
+    const size_t total = count * d * n;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t i = idx % n, j = (idx / n) % d, c = idx / (n * d);
+        const u64 v = pt[c * n + i] << (rounding_bits + (int)j * log_b);
+        rows_a[(c * 2 * d + j) * n + i] += v;
+        rows_b[(c * 2 * d + d + j) * n + i] += v;
+    }
+}
+
 // scheme/fhew/src/lwe.rs:128-139 `Lwe::sk_encrypt` for `rows` plaintexts: b[r] = <a[r], sk> + pt[r] + e[r] over any modulus q < 2^62
 // (q_ks = 2^16 in the reference's parameter sets).  NEG_POWER_UP: pt[r] = -sk1[r % n1] * base_{r / n1} (lwe.rs:108-119 `ksk_gen`:
 // `power_up(-sk1).flatten()`, digit-major), computed here instead of read.

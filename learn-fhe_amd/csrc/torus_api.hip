@@ -9,6 +9,7 @@
 #include "torus_kernels.hpp"
 #include "lwe_kernels.hpp"
 #include "torus30_kernels.hpp"
+#include "keygen_kernels.hpp"
 
 struct fhe_torus_ctx {
     int device = -1;
@@ -234,6 +235,33 @@ int fhe_torus_decompose(int log_b, int d, const uint64_t *in, size_t n, size_t p
 
 // exact a <- a * b in Z_{2^64}[X]/(X^n+1) (util/src/ring.rs:315-320 `Rt *= &Rt`), operands read as signed 64-bit integers;
 // log_bound_b: |b_i| < 2^log_bound_b.  Exactness needs n * 2^(63 + log_bound_b) < p0 p1 / 2.
+}  // extern "C"
+namespace {
+// a [batch][n] <- a * b (exact, mod 2^64) on device buffers; b [b_rows][n] cycled over the batch
+int torus_mul_dev(const fhe_torus_ctx *t, u64 *a, const u64 *b, size_t b_rows, int log_n, size_t batch, hipStream_t st) {
+    const size_t n = size_t(1) << log_n;
+    StreamWs wsp(2 * n * (batch + b_rows) * sizeof(u64), st);
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    u64 *ra = wsp.as<u64>(), *rb = ra + 2 * n * batch;  // adjacent: one forward launch over both
+    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)a, ra, n, batch, t->T.p0, t->T.p1);
+    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * b_rows)), dim3(256), 0, st, b, rb, n, b_rows, t->T.p0, t->T.p1);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(t->d_descs, 2, ra, log_n, 2 * (batch + b_rows), st, 60);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_pointwise_kernel, dim3(grid_for(2 * n * batch)), dim3(256), 0, st, ra, (const u64 *)rb, n, batch, b_rows, t->T.B0,
+                           t->T.B1);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = fhe::ntt_inv_multi(t->d_descs, 2, ra, log_n, 2 * batch, st, 60);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_crt_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ra, a, n, batch, t->T);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc;
+}
+}  // namespace
+extern "C" {
+
 int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int log_bound_b, size_t n, size_t batch, fhe_mem mem,
                   void *stream) {
     if (!t || !is_pow2(n) || ((!a || !b) && batch)) return FHE_ERR_INVALID;
@@ -246,24 +274,7 @@ int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int lo
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror ma(a, n * batch, mem, true, st), mb(b, n * batch, mem, true, st);
     if (ma.rc | mb.rc) return FHE_ERR_HIP;
-    StreamWs wsp(4 * n * batch * sizeof(u64), st);
-    if (wsp.rc != FHE_OK) return wsp.rc;
-    u64 *ws = wsp.as<u64>();
-    u64 *ra = ws, *rb = ws + 2 * n * batch;
-    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ma.d, ra, n, batch, t->T.p0, t->T.p1);
-    hipLaunchKernelGGL(fhe::torus_residue2_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)mb.d, rb, n, batch, t->T.p0, t->T.p1);
-    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
-    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(t->d_descs, 2, ra, log_n, 4 * batch, st, 60);  // ra and rb are adjacent
-    if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::torus_pointwise_kernel, dim3(grid_for(2 * n * batch)), dim3(256), 0, st, ra, (const u64 *)rb, n, batch, t->T.B0,
-                           t->T.B1);
-        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
-    }
-    if (rc == FHE_OK) rc = fhe::ntt_inv_multi(t->d_descs, 2, ra, log_n, 2 * batch, st, 60);
-    if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::torus_crt_kernel, dim3(grid_for(n * batch)), dim3(256), 0, st, (const u64 *)ra, ma.d, n, batch, t->T);
-        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
-    }
+    int rc = torus_mul_dev(t, ma.d, mb.d, batch, log_n, batch, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;
 }
@@ -510,6 +521,168 @@ int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_
                                  FHE_MEM_DEVICE, stream);
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
+    return rc;
+}
+
+// ---- TFHE key material on the device -----------------------------------------------------
+}  // extern "C"
+namespace {
+inline unsigned long long tdg_blocks(size_t count) { return (count + 3) / 4; }
+inline unsigned long long word_blocks(size_t count) { return (count + 7) / 8; }
+int sample_tdg_dev(double std_dev, const fhe::ChaChaKey &K, unsigned long long first, u64 *out, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(fhe::sample_tdg_kernel, dim3(grid_for(tdg_blocks(count))), dim3(256), 0, st, out, count, std_dev, K, first);
+    return hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+}
+// scheme/tfhe/src/tglwe.rs:91-103 (k = 1) for `rows` ciphertexts on device buffers: a uniform, e <- tdg, b = a s + e + pt
+// (pt [pt_rows][n] cycled, or null = encryptions of zero); sk [n], binary
+int tglwe_sk_encrypt_dev(const fhe_torus_ctx *t, const u64 *sk, const u64 *pt, size_t pt_rows, u64 *ct_a, u64 *ct_b, int log_n, size_t rows,
+                         double std_dev, const fhe::ChaChaKey &K, unsigned long long *cursor, hipStream_t st) {
+    const size_t n = size_t(1) << log_n, count = rows * n;
+    StreamWs we(count * sizeof(u64), st);
+    if (we.rc != FHE_OK) return we.rc;
+    u64 *e = we.as<u64>();
+    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(word_blocks(count))), dim3(256), 0, st, ct_a, count, K, *cursor);
+    *cursor += word_blocks(count);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = sample_tdg_dev(std_dev, K, *cursor, e, count, st);
+    *cursor += tdg_blocks(count);
+    if (rc == FHE_OK && hipMemcpyAsync(ct_b, ct_a, count * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = torus_mul_dev(t, ct_b, sk, 1, log_n, rows, st);  // a binary key: |s_i| <= 1, far inside the exact range
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::torus_add3_kernel, dim3(grid_for(count)), dim3(256), 0, st, ct_b, (const u64 *)e, pt, count, pt ? pt_rows * n : 1);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc;
+}
+int torus_ring_ok(const fhe_torus_ctx *t, size_t n) {
+    if (!t || !is_pow2(n)) return FHE_ERR_INVALID;
+    if (t->device < 0) return FHE_ERR_NO_DEVICE;
+    const int log_n = ilog2(n);
+    return (log_n < 1 || log_n > 15) ? FHE_ERR_UNSUPPORTED : FHE_OK;
+}
+}  // namespace
+extern "C" {
+
+int fhe_sample_tdg(double std_dev, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!(std_dev >= 0) || (!out && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    int rc = sample_tdg_dev(std_dev, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    return rc == FHE_OK ? mo.sync_out(st) : rc;
+}
+
+int fhe_sample_binary(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!out && count) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    hipLaunchKernelGGL(fhe::sample_binary_kernel, dim3(grid_for((count + 511) / 512)), dim3(64), 0, st, mo.d, count, fhe::chacha_key(seed, stream_id), 0ull);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/tfhe/src/tlwe.rs:122-132 for `rows` plaintexts: out_a [rows][n] uniform torus, out_b[r] = <a[r], sk> + e + pt[r]
+int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed, uint64_t stream_id,
+                        uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!sk || n == 0 || !(std_dev >= 0) || ((!out_a || !out_b) && rows)) return FHE_ERR_INVALID;
+    if (rows == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? rows : 0, mem, true, st), ma(out_a, rows * n, mem, false, st), mb(out_b, rows, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs we(rows * sizeof(u64), st);
+    if (we.rc != FHE_OK) return we.rc;
+    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
+    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(word_blocks(rows * n))), dim3(256), 0, st, ma.d, rows * n, K, 0ull);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = sample_tdg_dev(std_dev, K, word_blocks(rows * n), we.as<u64>(), rows, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::tlwe_encrypt_kernel, dim3(grid_for(rows)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)msk.d, (const u64 *)we.as<u64>(),
+                           pt ? (const u64 *)mpt.d : nullptr, mb.d, n, rows, (const u64 *)nullptr, (size_t)1, 0, 0);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// scheme/tfhe/src/tlwe.rs:100-111 `Tlwe::ksk_gen(param, sk0, sk1)`: rows r = j n1 + i encrypt -sk1[i] 2^(rb + j log_b) under sk0:
+// ksk_a [n1 d][n0], ksk_b [n1 d], the layout fhe_tlwe_key_switch takes
+int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, uint64_t seed,
+                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+    if (log_b < 1 || d < 1 || log_b * d > 64 || !sk0 || !sk1 || n0 == 0 || n1 == 0 || !ksk_a || !ksk_b || !(std_dev >= 0)) return FHE_ERR_INVALID;
+    PtrDeviceGuard pguard(ksk_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = n1 * d;
+    Mirror m0(sk0, n0, mem, true, st), m1(sk1, n1, mem, true, st), ma(ksk_a, rows * n0, mem, false, st), mb(ksk_b, rows, mem, false, st);
+    if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs we(rows * sizeof(u64), st);
+    if (we.rc != FHE_OK) return we.rc;
+    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
+    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(word_blocks(rows * n0))), dim3(256), 0, st, ma.d, rows * n0, K, 0ull);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = sample_tdg_dev(std_dev, K, word_blocks(rows * n0), we.as<u64>(), rows, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::tlwe_encrypt_kernel, dim3(grid_for(rows)), dim3(256), 0, st, (const u64 *)ma.d, (const u64 *)m0.d, (const u64 *)we.as<u64>(),
+                           (const u64 *)nullptr, mb.d, n0, rows, (const u64 *)m1.d, n1, 64 - log_b * d, log_b);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// scheme/tfhe/src/tglwe.rs:91-103 (k = 1): ct_a, ct_b [rows][n]; pt [rows][n] or NULL (zeros); sk [n] binary
+int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed,
+                         uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+    int rc = torus_ring_ok(t, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || !(std_dev >= 0) || ((!ct_a || !ct_b) && rows)) return FHE_ERR_INVALID;
+    if (rows == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? rows * n : 0, mem, true, st), ma(ct_a, rows * n, mem, false, st), mb(ct_b, rows * n, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    unsigned long long cursor = 0;
+    rc = tglwe_sk_encrypt_dev(t, msk.d, pt ? mpt.d : nullptr, rows, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// scheme/tfhe/src/tggsw.rs:73-88 (k = 1) for `count` plaintext polynomials pt [count][n]: rows_a, rows_b [count][2d][n], the
+// layout fhe_tggsw_prepare takes
+int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, double std_dev,
+                      uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    int rc = torus_ring_ok(t, n);
+    if (rc != FHE_OK) return rc;
+    if (log_b < 1 || d < 1 || log_b * d > 64 || !sk || !(std_dev >= 0) || ((!pt || !rows_a || !rows_b) && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * 2 * d;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, count * n, mem, true, st), ma(rows_a, rows * n, mem, false, st), mb(rows_b, rows * n, mem, false, st);
+    if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    unsigned long long cursor = 0;
+    rc = tglwe_sk_encrypt_dev(t, msk.d, nullptr, 0, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::tggsw_add_gadget_kernel, dim3(grid_for(count * d * n)), dim3(256), 0, st, ma.d, mb.d, (const u64 *)mpt.d, n, count, d,
+                           64 - log_b * d, log_b);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
 }
 

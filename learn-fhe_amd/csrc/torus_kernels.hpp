@@ -259,12 +259,13 @@ FHE_HEADER_KERNEL void torus_residue2_kernel(const u64 *__restrict__ in, u64 *__
     }
 }
 
-// ra <- ra (.) rb per prime; [batch][2][n]
-FHE_HEADER_KERNEL void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *__restrict__ rb, size_t n, size_t batch, Barrett B0, Barrett B1) {
-    const size_t total = 2 * n * batch;
+// ra <- ra (.) rb per prime; ra [batch][2][n], rb [b_rows][2][n] cycled over the batch (b_rows = 1: one multiplier for all)
+FHE_HEADER_KERNEL void torus_pointwise_kernel(u64 *__restrict__ ra, const u64 *__restrict__ rb, size_t n, size_t batch, size_t b_rows, Barrett B0,
+                                              Barrett B1) {
+    const size_t total = 2 * n * batch, period = 2 * n * b_rows;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const bool second = (idx / n) & 1;
-        ra[idx] = mulmod_barrett(ra[idx], rb[idx], second ? B1 : B0);
+        ra[idx] = mulmod_barrett(ra[idx], rb[idx % period], second ? B1 : B0);
     }
 }
 

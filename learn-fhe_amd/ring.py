@@ -705,3 +705,56 @@ def rq_sum(q, a, n):
     po, _, _, _ = _buf(out)
     L.check(L.lib().fhe_rq_sum(q, p, n, cnt // n, po, mem, st), "fhe_rq_sum")
     return out
+
+
+def sample_tdg(std_dev, seed, stream_id, like, count):
+    """util/src/misc/distribution.rs:49-54"""
+    out = _like(like, (count,))
+    po, _, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_tdg(std_dev, seed, stream_id, po, count, mem, st), "fhe_sample_tdg")
+    return out
+
+
+def sample_binary(seed, stream_id, like, count):
+    """distribution.rs `binary()`"""
+    out = _like(like, (count,))
+    po, _, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_binary(seed, stream_id, po, count, mem, st), "fhe_sample_binary")
+    return out
+
+
+def tlwe_sk_encrypt(sk, pt, n, rows, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tlwe.rs:122-132 -> (a [rows][n], b [rows])"""
+    ps, _, mem, st = _buf(sk)
+    pp = _buf(pt)[0] if pt is not None else None
+    a, b = _like(sk, (rows, n)), _like(sk, (rows,))
+    L.check(L.lib().fhe_tlwe_sk_encrypt(ps, pp, n, rows, std_dev, seed, stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tlwe_sk_encrypt")
+    return a, b
+
+
+def tlwe_ksk_gen(log_b, d, sk0, sk1, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tlwe.rs:100-111 -> (ksk_a [n1 d][n0], ksk_b [n1 d])"""
+    p0, n0, mem, st = _buf(sk0)
+    p1, n1, _, _ = _buf(sk1)
+    ka, kb = _like(sk0, (n1 * d, n0)), _like(sk0, (n1 * d,))
+    L.check(L.lib().fhe_tlwe_ksk_gen(log_b, d, p0, n0, p1, n1, std_dev, seed, stream_id, _buf(ka)[0], _buf(kb)[0], mem, st), "fhe_tlwe_ksk_gen")
+    return ka, kb
+
+
+def tglwe_sk_encrypt(t, sk, pt, n, rows, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tglwe.rs:91-103 -> (a, b) [rows][n]"""
+    ps, _, mem, st = _buf(sk)
+    pp = _buf(pt)[0] if pt is not None else None
+    a, b = _like(sk, (rows, n)), _like(sk, (rows, n))
+    L.check(L.lib().fhe_tglwe_sk_encrypt(t.handle, ps, pp, n, rows, std_dev, seed, stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tglwe_sk_encrypt")
+    return a, b
+
+
+def tggsw_encrypt(t, log_b, d, sk, pt, n, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tggsw.rs:73-88 for pt [count][n] -> (rows_a, rows_b) [count][2d][n]"""
+    ps, _, mem, st = _buf(sk)
+    pp, cnt, _, _ = _buf(pt)
+    count = cnt // n
+    ra, rb = _like(sk, (count, 2 * d, n)), _like(sk, (count, 2 * d, n))
+    L.check(L.lib().fhe_tggsw_encrypt(t.handle, log_b, d, ps, pp, n, count, std_dev, seed, stream_id, _buf(ra)[0], _buf(rb)[0], mem, st), "fhe_tggsw_encrypt")
+    return ra, rb

@@ -199,3 +199,65 @@ def test_rq_sum(fhe, torch_cuda):
         exp = [sum(int(a[k, i]) for k in range(count)) % q for i in range(n)]
         assert L(host(fhe.rq_sum(q, dev(torch_cuda, a), n))) == exp
         assert L(fhe.rq_sum(q, a, n)) == exp
+
+
+def test_tfhe_bootstrap_with_device_made_keys(fhe, torch_cuda):
+    """The reference's own `bootstrap` test (scheme/tfhe/src/bootstrapping.rs:139-165) with ITS parameter set -- big_n = 2048,
+    k = 1, base 2^23 x 1, n_lwe = 1024, key switch (4, 5), log_p 4, padding 1, std_dev 1.34e-7 (TLWE) / 2.85e-15 (TGGSW) -- and every
+    key and ciphertext made by the device-side producers: `Tlwe::sk_gen` (binary), `Bootstrapping::key_gen` (bootstrapping.rs:59-76:
+    brk_i = TGGSW(z_i) under s, ksk = Tlwe::ksk_gen(z, s)), `Tlwe::sk_encrypt`; LUTs identity / double / parity over all 16 messages
+    through the single-call gate, decoded on the host (tlwe.rs:134-142)."""
+    from oracle import pyref as P
+    n, n_lwe, log_p, padding, log_b, d, ks_lb, ks_d = 2048, 1024, 4, 1, 23, 1, 4, 5
+    sd_lwe, sd_glwe = 1.339775301998614e-7, 2.845267479601915e-15
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    like = dev(torch_cuda, U([0]))
+    t = fhe.TorusContext()
+    z, s = fhe.sample_binary(700, 0, like, n_lwe), fhe.sample_binary(700, 1, like, n)
+    zh = L(host(z))
+    assert set(zh) == {0, 1} and 0.4 < sum(zh) / n_lwe < 0.6
+    pt = np.zeros((n_lwe, n), dtype=np.uint64)
+    pt[:, 0] = host(z)                                            # Rt::constant(z_i) (bootstrapping.rs:66-67)
+    ra, rb = fhe.tggsw_encrypt(t, log_b, d, s, dev(torch_cuda, pt), n, sd_glwe, 701, 0)
+    key = fhe.TggswKey(t, log_b, d, ra, rb, n)
+    ksa, ksb = fhe.tlwe_ksk_gen(ks_lb, ks_d, z, s, sd_lwe, 702, 0)
+
+    def table(f):
+        m_ = n >> log_p
+        tt = [f(v) % p for v in range(p)]
+        out = [tt[0]] * (m_ // 2)
+        for x in tt[1:]:
+            out += [x] * m_
+        return out + [(-tt[0]) % p] * (m_ // 2)
+
+    for li, f in enumerate((lambda v: v, lambda v: 2 * v, lambda v: v % 2)):
+        v = dev(torch_cuda, U([(x << log_delta) % P.M64 for x in table(f)]))
+        msgs = dev(torch_cuda, U([(m << log_delta) % P.M64 for m in range(p)]))
+        ca, cb = fhe.tlwe_sk_encrypt(z, msgs, n_lwe, p, sd_lwe, 703, li)
+        for m in range(p):                                         # the inputs decrypt to their messages (tlwe.rs:134-142)
+            mu = ((P.tlwe_phase(zh, L(host(ca)[m]), int(host(cb)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
+            assert mu % p == m
+        oa, ob = key.bootstrap(ks_lb, ks_d, ksa, ksb, v, ca, cb)
+        for m in range(p):
+            mu = ((P.tlwe_phase(zh, L(host(oa)[m]), int(host(ob)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
+            assert mu % p == f(m) % p, (li, m, mu)
+
+
+def test_tdg_and_tglwe_encrypt(fhe, torch_cuda):
+    """`tdg` (distribution.rs:49-54): centred, the standard deviation asked for (as a fraction of the torus); `Tglwe::sk_encrypt`
+    (tglwe.rs:91-103): b - a s - pt is that noise, with a s the exact product of row T"""
+    from oracle import cref
+    like = dev(torch_cuda, U([0]))
+    sd = 2.0 ** -20
+    e = host(fhe.sample_tdg(sd, 9, 0, like, 1 << 16)).view(np.int64).astype(np.float64) / 2.0 ** 64
+    assert abs(e.mean()) < 4 * sd / 256 and 0.97 * sd < e.std() < 1.03 * sd
+    assert np.array_equal(host(fhe.sample_tdg(sd, 9, 0, like, 100)), host(fhe.sample_tdg(sd, 9, 0, like, 1 << 16))[:100])
+    n, rows = 512, 3
+    t = fhe.TorusContext()
+    s = fhe.sample_binary(10, 0, like, n)
+    rng = np.random.Generator(np.random.PCG64(3))
+    pt = rng.integers(0, 1 << 63, size=(rows, n), dtype=np.uint64)
+    a, b = fhe.tglwe_sk_encrypt(t, s, dev(torch_cuda, pt), n, rows, sd, 11, 0)
+    for r in range(rows):
+        noise = (host(b)[r] - cref.torus_mul_exact(host(a)[r], host(s)) - pt[r]).view(np.int64).astype(np.float64) / 2.0 ** 64
+        assert abs(noise).max() < 6 * sd and noise.std() > 0.5 * sd
