@@ -306,6 +306,18 @@ int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0
                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
 /* util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q, in [count][len] (callers used to loop fhe_rq_add) */
 int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream);
+/* ---- CKKS key material (scheme/ckks/src/ckks.rs:139-183, 215-225).  Secret keys are two's-complement i64 vectors. */
+/* util/src/misc/distribution.rs:10-21 `zo(rho)` (ckks.rs:139-141 `Ckks::sk_gen`: rho = 0.5): -1 / +1 / 0 as i64 */
+int fhe_sample_zo(double rho, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+/* ckks.rs:215-225 `Ckks::sk_encrypt` for `batch` plaintexts over qs (extended = 0) or qs ++ ps: b = -(a sk) + e + pt, a uniform,
+ * e <- dg(3.2, 6).  pt [batch][limbs][n] or NULL (zeros: ckks.rs:143-146 `pk_gen`); out_b, out_a [batch][limbs][n]. */
+int fhe_ckks_sk_encrypt(const fhe_rns_ctx *rns, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
+                        uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream);
+/* ckks.rs:154-161 `Ckks::ksk_gen(param, sk, sk_prime)` -> ksk_b, ksk_a [L+K][n] for fhe_ckks_ksk_prepare.  sk_prime NULL: sk^2
+ * (ckks.rs:163-166 `rlk_gen`), squared on the device; `cjk_gen` / `rtk_gen` (ckks.rs:168-183): sk_prime = sk(X^t), t = -1 / 5^j. */
+int fhe_ckks_ksk_gen(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *sk_prime, size_t n, uint64_t seed, uint64_t stream_id,
+                     uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream);
+
 /* ---- TFHE key material, k = 1.  Draws are counter based (ChaCha20, as above): reproducible per
  * (seed, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
 /* util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: torus Gaussian noise (Box-Muller deviate, fractional part scaled by 2^64) */

@@ -122,6 +122,9 @@ def lib():
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
         u64, dbl = C.c_uint64, C.c_double
+        L.fhe_sample_zo.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
+        L.fhe_ckks_sk_encrypt.argtypes = [vp, ci, vp, vp, sz, sz, u64, u64, vp, vp, ci, vp]
+        L.fhe_ckks_ksk_gen.argtypes = [vp, vp, vp, sz, u64, u64, vp, vp, ci, vp]
         L.fhe_sample_tdg.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
         L.fhe_sample_binary.argtypes = [u64, u64, vp, sz, ci, vp]
         L.fhe_tlwe_sk_encrypt.argtypes = [vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]

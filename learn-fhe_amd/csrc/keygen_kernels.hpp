@@ -129,6 +129,58 @@ FHE_HEADER_KERNEL void add_assign_kernel(u64 *__restrict__ out, const u64 *__res
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) out[i] = csub(out[i] + add[i], q);
 }
 
+// util/src/misc/distribution.rs:10-21 `zo(rho)`: -1 with probability rho / 2, +1 with rho / 2, 0 otherwise; two's-complement i64
+// (scheme/ckks/src/ckks.rs:139-141 `Ckks::sk_gen`: rho = 0.5)
+FHE_HEADER_KERNEL void sample_zo_kernel(u64 *__restrict__ out, size_t count, double rho, ChaChaKey K, unsigned long long first) {
+    for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 8 < count; blk += size_t(gridDim.x) * blockDim.x) {
+        unsigned long long w[8];
+        chacha20_block(K, first + blk, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (blk * 8 + j >= count) continue;
+            const double v = (double)(w[j] >> 11) * (1.0 / 9007199254740992.0);  // `Standard` f64: [0, 1)
+            out[blk * 8 + j] = v <= rho / 2.0 ? ~0ull : (v <= rho ? 1ull : 0ull);
+        }
+    }
+}
+
+// util/src/ring/rns.rs:61-63 `RnsRq::from_i64`: out[l][i] = v[i] mod m_l (zq.rs:63-69), v two's-complement i64, times mult[l] if given
+FHE_HEADER_KERNEL void rns_from_i64_kernel(const u64 *__restrict__ v, u64 *__restrict__ out, size_t n, int limbs, const Barrett *__restrict__ B,
+                                           const u64 *__restrict__ mult) {
+    const size_t total = n * limbs;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t l = idx / n, i = idx - l * n;
+        const Barrett b = B[l];
+        const long long x = (long long)v[i];
+        u64 r = x < 0 ? (u64)(-x) % b.q : (u64)x % b.q;
+        if (x < 0 && r) r = b.q - r;
+        out[idx] = mult ? mulmod_barrett(r, mult[l], b) : r;
+    }
+}
+// scheme/ckks/src/ckks.rs:222: b <- -(a s) + e + pt over [batch][limbs][n]; e [batch][n] i64; pt [batch or 1][limbs][n] or null
+FHE_HEADER_KERNEL void ckks_finish_b_kernel(u64 *__restrict__ b, const u64 *__restrict__ e, const u64 *__restrict__ pt, size_t n, int limbs, size_t batch,
+                                            size_t pt_batch, const Barrett *__restrict__ B) {
+    const size_t total = batch * limbs * n;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t i = idx % n, l = (idx / n) % limbs, c = idx / (n * limbs);
+        const u64 q = B[l].q;
+        const long long x = (long long)e[c * n + i];
+        u64 ev = x < 0 ? (u64)(-x) % q : (u64)x % q;
+        if (x < 0 && ev) ev = q - ev;
+        const u64 as = b[idx];
+        u64 r = csub((as ? q - as : 0) + ev, q);
+        if (pt) r = csub(r + pt[((c % pt_batch) * limbs + l) * n + i], q);
+        b[idx] = r;
+    }
+}
+// centred lift of a polynomial mod q to two's-complement i64 (the integer square of a small secret key, ckks.rs:78-80)
+FHE_HEADER_KERNEL void centre_to_i64_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const u64 v = in[i];
+        out[i] = v > q / 2 ? (u64)(-(long long)(q - v)) : v;
+    }
+}
+
 // util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: v ~ N(0, std_dev), frac = v - round(v), T64 = round(frac 2^64) as i64
 // (Rust's float -> int cast saturates).  The normal deviate is Box-Muller on two words of the generator: the reference's
 // `rand_distr::Normal` is a different sampler of the same distribution, and its draws are unseeded.

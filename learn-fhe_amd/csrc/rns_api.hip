@@ -1,6 +1,7 @@
 // extern "C" entry points for SURVEY.md section 8(a) row a14: RNS base extension, rescale_k, CKKS key switch.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <set>
@@ -9,6 +10,7 @@
 #include "api_common.hpp"
 #include "ctx.hpp"
 #include "rns_kernels.hpp"
+#include "keygen_kernels.hpp"
 
 struct fhe_rns_ctx {
     int L = 0, K = 0, device = -1;
@@ -510,6 +512,170 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
     }
     if (rc == FHE_OK) rc = mob.sync_out(st);
     if (rc == FHE_OK) rc = moa.sync_out(st);
+    return rc;
+}
+
+// ---- CKKS key material on the device (scheme/ckks/src/ckks.rs:139-183, 215-225) ---------------------------------------------
+}  // extern "C"
+namespace {
+// distribution.rs:25-45 `dg(3.2, 6)` cumulative weights, as in keygen_api.hip
+int ckks_dg_table(fhe::DgTable *T) {
+    const double std_dev = 3.2;
+    auto erf_as = [](double x) {
+        const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
+        const double t = 1.0 / (1.0 + p * std::fabs(x));
+        const double pos = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+        return std::signbit(x) ? -pos : pos;
+    };
+    auto cdf = [&](double x) { return (1.0 + erf_as(x / (std_dev * 1.4142135623730951))) / 2.0; };
+    const long long mx = (long long)std::floor(6.0 * std_dev);
+    T->max = (int)mx; T->len = (int)(2 * mx + 1);
+    double acc = 0;
+    for (long long i = -mx; i <= mx; ++i) { acc += cdf((double)i + 0.5) - cdf((double)i - 0.5); T->cum[i + mx] = acc; }
+    return FHE_OK;
+}
+
+// ckks.rs:215-225 on device buffers over the first `limbs` moduli of qs ++ ps: a uniform, e <- dg(3.2, 6), b = -(a s) + e + pt.
+// sk [n] two's-complement i64; pt [pt_batch][limbs][n] or null; out_b, out_a [batch][limbs][n]
+int ckks_sk_encrypt_dev(const fhe_rns_ctx *r, int limbs, const u64 *sk, const u64 *pt, size_t pt_batch, u64 *out_b, u64 *out_a, int log_n,
+                        size_t batch, const fhe::ChaChaKey &K, unsigned long long *cursor, hipStream_t st) {
+    const size_t n = size_t(1) << log_n;
+    StreamWs ws((size_t(limbs) * n + batch * n) * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *s_eval = ws.as<u64>(), *e = s_eval + size_t(limbs) * n;
+    hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(n * limbs)), dim3(256), 0, st, sk, s_eval, n, limbs, (const fhe::Barrett *)r->d_barrett,
+                       (const u64 *)nullptr);
+    int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)limbs, s_eval, log_n, limbs, st, r->all_pm);
+    for (size_t c = 0; c < batch && rc == FHE_OK; ++c)
+        for (int l = 0; l < limbs && rc == FHE_OK; ++l) {  // one modulus per launch: set-up code
+            const uint64_t m = l < r->L ? r->qs[l] : r->ps[l - r->L];
+            hipLaunchKernelGGL(fhe::sample_uniform_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, out_a + (c * limbs + l) * n, n, fhe::make_barrett(m), K,
+                               *cursor);
+            *cursor += (n + 3) / 4;
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+    fhe::DgTable T;
+    ckks_dg_table(&T);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::sample_dg_kernel, dim3(grid_for((batch * n + 7) / 8)), dim3(256), 0, st, e, batch * n, (u64)0, T, K, *cursor);
+        *cursor += (batch * n + 7) / 8;
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) {  // a s: forward of a out of place into b, inverse with the evaluation-domain key on its load (limb s % limbs)
+        fhe::NttIo src;
+        src.src = out_a; src.src_mod = (unsigned)(batch * limbs);
+        rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)limbs, out_b, log_n, batch * limbs, st, r->all_pm, src);
+    }
+    if (rc == FHE_OK) {
+        fhe::NttIo mul;
+        mul.mul = s_eval; mul.mul_div = (unsigned)(batch * limbs); mul.mul_period = (unsigned)limbs;
+        rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)limbs, out_b, log_n, batch * limbs, st, r->all_pm, mul);
+    }
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::ckks_finish_b_kernel, dim3(grid_for(batch * limbs * n)), dim3(256), 0, st, out_b, (const u64 *)e, pt, n, limbs, batch,
+                           pt ? pt_batch : 1, (const fhe::Barrett *)r->d_barrett);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc;
+}
+
+int ckks_ring_ok(const fhe_rns_ctx *r, size_t n) {
+    if (!r || !is_pow2(n) || n < 2) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    for (const fhe_ctx *c : r->mods)
+        if (ilog2(n) > c->s - 1) return FHE_ERR_NO_ROOT;
+    return ilog2(n) > r->max_log_n ? FHE_ERR_UNSUPPORTED : FHE_OK;
+}
+}  // namespace
+extern "C" {
+
+// util/src/misc/distribution.rs:10-21 `zo(rho)` as two's-complement i64 (ckks.rs:139-141 `Ckks::sk_gen`: rho = 0.5)
+int fhe_sample_zo(double rho, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!(rho >= 0 && rho <= 1.0) || (!out && count)) return FHE_ERR_INVALID;  // `assert!(rho <= 1.0)`
+    if (count == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror mo(out, count, mem, false, st);
+    if (mo.rc != FHE_OK) return mo.rc;
+    hipLaunchKernelGGL(fhe::sample_zo_kernel, dim3(grid_for((count + 7) / 8)), dim3(256), 0, st, mo.d, count, rho, fhe::chacha_key(seed, stream_id), 0ull);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// scheme/ckks/src/ckks.rs:215-225 `Ckks::sk_encrypt` for `batch` plaintexts over qs (extended = 0) or qs ++ ps: sk [n] i64;
+// pt [batch][limbs][n] or NULL (zeros: ckks.rs:143-146 `pk_gen`); out_b, out_a [batch][limbs][n], coefficient domain
+int fhe_ckks_sk_encrypt(const fhe_rns_ctx *r, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
+                        uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream) {
+    int rc = ckks_ring_ok(r, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || ((!out_b || !out_a) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int limbs = extended ? r->L + r->K : r->L;
+    const size_t words = batch * limbs * n;
+    Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? words : 0, mem, true, st), mb(out_b, words, mem, false, st), ma(out_a, words, mem, false, st);
+    if (msk.rc | mpt.rc | mb.rc | ma.rc) return FHE_ERR_HIP;
+    unsigned long long cursor = 0;
+    rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt ? mpt.d : nullptr, batch, mb.d, ma.d, ilog2(n), batch, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    return rc;
+}
+
+// scheme/ckks/src/ckks.rs:154-161 `Ckks::ksk_gen(param, sk, sk_prime)`: an encryption of sk' * P over qs ++ ps under sk.
+// sk_prime NULL: sk' = sk^2 (ckks.rs:163-166 `rlk_gen`), the integer negacyclic square computed on the device.  For
+// `cjk_gen` / `rtk_gen` (ckks.rs:168-183) pass sk(X^t), t = -1 / 5^j.  ksk_b, ksk_a [L+K][n], what fhe_ckks_ksk_prepare takes.
+int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *sk_prime, size_t n, uint64_t seed, uint64_t stream_id,
+                     uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream) {
+    int rc = ckks_ring_ok(r, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || !ksk_b || !ksk_a) return FHE_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int limbs = r->L + r->K, log_n = ilog2(n);
+    const size_t words = size_t(limbs) * n;
+    Mirror msk(sk, n, mem, true, st), msp(sk_prime, sk_prime ? n : 0, mem, true, st), mb(ksk_b, words, mem, false, st), ma(ksk_a, words, mem, false, st);
+    if (msk.rc | msp.rc | mb.rc | ma.rc) return FHE_ERR_HIP;
+    StreamWs ws((words + 2 * n + limbs) * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *pt = ws.as<u64>(), *sq = pt + words, *d_pm = sq + 2 * n;
+    const u64 *spr = msp.d;
+    if (!sk_prime) {  // sk^2 over Z: |coefficient| <= n, far below q_0 / 2, so the square mod q_0 lifts back exactly
+        hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const u64 *)msk.d, sq, n, 1, (const fhe::Barrett *)r->d_barrett,
+                           (const u64 *)nullptr);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(r->d_descs, 1, sq, log_n, 1, st, r->mods[0]->pm_b);
+        if (rc == FHE_OK) {
+            fhe::NttIo io;
+            io.mul = sq; io.mul_div = 1; io.mul_period = 1;
+            if (hipMemcpyAsync(sq + n, sq, n * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+            if (rc == FHE_OK) rc = fhe::ntt_inv_multi(r->d_descs, 1, sq + n, log_n, 1, st, r->mods[0]->pm_b, io);
+        }
+        if (rc == FHE_OK) {
+            hipLaunchKernelGGL(fhe::centre_to_i64_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const u64 *)(sq + n), sq, n, (u64)r->qs[0]);
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+        spr = sq;
+    }
+    // pt = RnsRq::from_i64(qps, sk') * P (ckks.rs:160): P mod p_j = 0, so the p-limbs of pt vanish
+    std::vector<uint64_t> pm(limbs);
+    for (int l = 0; l < limbs; ++l) pm[l] = prod_mod(r->ps, -1, l < r->L ? r->qs[l] : r->ps[l - r->L]);
+    if (rc == FHE_OK && hipMemcpyAsync(d_pm, pm.data(), limbs * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK && hipStreamSynchronize(st) != hipSuccess) rc = FHE_ERR_HIP;  // pm is a stack-owned vector
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(words)), dim3(256), 0, st, spr, pt, n, limbs, (const fhe::Barrett *)r->d_barrett,
+                           (const u64 *)d_pm);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    unsigned long long cursor = 0;
+    if (rc == FHE_OK) rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt, 1, mb.d, ma.d, log_n, 1, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;
 }
 

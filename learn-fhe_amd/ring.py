@@ -389,6 +389,24 @@ class RnsContext:
         L.check(L.lib().fhe_rns_rescale(self._h, p, po, n, batch, mem, st), "fhe_rns_rescale")
         return out
 
+    def sk_encrypt(self, sk, pt, n, batch, seed, stream_id, extended=False):
+        """scheme/ckks/src/ckks.rs:215-225 -> (b, a) [batch][limbs][n]; sk [n] i64; pt [batch][limbs][n] or None."""
+        ps, _, mem, st = _buf(sk)
+        pp = _buf(pt)[0] if pt is not None else None
+        limbs = self.L + self.K if extended else self.L
+        b, a = _like(sk, (batch, limbs, n)), _like(sk, (batch, limbs, n))
+        L.check(L.lib().fhe_ckks_sk_encrypt(self._h, int(extended), ps, pp, n, batch, seed, stream_id, _buf(b)[0], _buf(a)[0], mem, st),
+                "fhe_ckks_sk_encrypt")
+        return b, a
+
+    def ksk_gen(self, sk, sk_prime, n, seed, stream_id):
+        """scheme/ckks/src/ckks.rs:154-183 -> (ksk_b, ksk_a) [L+K][n]; sk_prime None = sk^2 (the relinearisation key)."""
+        ps, _, mem, st = _buf(sk)
+        pp = _buf(sk_prime)[0] if sk_prime is not None else None
+        kb, ka = _like(sk, (self.L + self.K, n)), _like(sk, (self.L + self.K, n))
+        L.check(L.lib().fhe_ckks_ksk_gen(self._h, ps, pp, n, seed, stream_id, _buf(kb)[0], _buf(ka)[0], mem, st), "fhe_ckks_ksk_gen")
+        return kb, ka
+
     def automorphism(self, limbs, t, n):
         """ckks.rs:127-129 on [batch][L][n]."""
         p, cnt, mem, st = _buf(limbs)
@@ -758,3 +776,11 @@ def tggsw_encrypt(t, log_b, d, sk, pt, n, std_dev, seed, stream_id):
     ra, rb = _like(sk, (count, 2 * d, n)), _like(sk, (count, 2 * d, n))
     L.check(L.lib().fhe_tggsw_encrypt(t.handle, log_b, d, ps, pp, n, count, std_dev, seed, stream_id, _buf(ra)[0], _buf(rb)[0], mem, st), "fhe_tggsw_encrypt")
     return ra, rb
+
+
+def sample_zo(rho, seed, stream_id, like, count):
+    """util/src/misc/distribution.rs:10-21 as two's-complement i64"""
+    out = _like(like, (count,))
+    po, _, mem, st = _buf(out)
+    L.check(L.lib().fhe_sample_zo(rho, seed, stream_id, po, count, mem, st), "fhe_sample_zo")
+    return out

@@ -354,3 +354,68 @@ def test_ckks_mul_rotate_decrypt(fhe, torch_cuda):
         big = 1 << 62
         want = [x - big if x > big // 2 else x for x in P.automorphism(big, [(delta * x) % big for x in m0], t)]
         assert max(abs(g - w) for g, w in zip(got, want)) < 2 ** 16, t
+
+
+def test_ckks_device_keys_decrypt_level(fhe, torch_cuda):
+    """`Ckks::sk_gen` / `sk_encrypt` / `rlk_gen` / `rtk_gen` / `cjk_gen` (scheme/ckks/src/ckks.rs:139-183, 215-225) on the device, then
+    `mul`, `rotate`, `conjugate` on those keys; checked as the reference checks them (ckks.rs:378-420), at decrypt level on the host."""
+    from oracle import pyref as P
+    log_n, bits, big_l = 7, 50, 3
+    n = 1 << log_n
+    allp, it = [], P.two_adic_primes(bits, log_n + 1)
+    while len(allp) < 2 * big_l:
+        allp.append(next(it))
+    qs, ps = allp[:big_l], allp[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    like = dev(torch_cuda, np.zeros(1, dtype=np.uint64))
+    sk_d = fhe.sample_zo(0.5, 50, 0, like, n)
+    sk = [int(x) for x in host(sk_d).view(np.int64)]
+    assert set(sk) <= {-1, 0, 1} and 0.3 < sum(1 for x in sk if x) / n < 0.7
+    lift = lambda mods, v: [[x % m for x in v] for m in mods]  # noqa: E731
+
+    def decrypt(mods, b, a):  # ckks.rs:241-248 + centred CRT
+        a_s = P.rns_mul(mods, a, lift(mods, sk))
+        pt = [[(x + y) % m for x, y in zip(rb, ra)] for m, rb, ra in zip(mods, b, a_s)]
+        big_q = math.prod(mods)
+        out = []
+        for i in range(n):
+            v = sum(row[i] * (big_q // m) * pow(big_q // m, -1, m) for m, row in zip(mods, pt)) % big_q
+            out.append(v - big_q if v > big_q // 2 else v)
+        return out
+
+    rows = lambda t: [L_(r) for r in host(t)]  # noqa: E731
+    rnd = random.Random(3)
+    delta = 1 << 45
+    ms = [[rnd.randint(-5, 5) for _ in range(n)] for _ in range(2)]
+    pts = np.array([[[(delta * x) % m for x in mm] for m in qs] for mm in ms], dtype=np.uint64)
+    b, a = rns.sk_encrypt(sk_d, dev(torch_cuda, pts), n, 2, 51, 0)
+    for c in range(2):
+        got = decrypt(qs, rows(b[c]), rows(a[c]))
+        assert max(abs(g - delta * w) for g, w in zip(got, ms[c])) < 64        # e <- dg(3.2, 6): |e| <= 19
+    # a fresh encryption of zero is not zero, and two draws differ
+    zb, za = rns.sk_encrypt(sk_d, None, n, 1, 51, 1)
+    assert max(abs(x) for x in decrypt(qs, rows(zb[0]), rows(za[0]))) <= 19 and not np.array_equal(host(za[0]), host(a[0]))
+    # mul on the device-made relinearisation key
+    rlk = fhe.CkksKey(rns, *rns.ksk_gen(sk_d, None, n, 52, 0), n)
+    ob, oa = rlk.mul(b[0:1].contiguous(), a[0:1].contiguous(), b[1:2].contiguous(), a[1:2].contiguous())
+    got = decrypt(qs[:-1], rows(ob[0]), rows(oa[0]))
+    want = [0] * n
+    for i, x in enumerate(ms[0]):
+        for j, y in enumerate(ms[1]):
+            if i + j < n:
+                want[i + j] += x * y
+            else:
+                want[i + j - n] -= x * y
+    scale2 = delta * delta / qs[-1]
+    assert max(abs(g - scale2 * w) for g, w in zip(got, want)) < 2 ** 18
+    # rotate / conjugate on device-made keys: sk' = sk(X^t)
+    for t in (pow(5, 3, 2 * n), -1):
+        big = 1 << 62
+        cen = lambda v: [x - big if x > big // 2 else x for x in v]  # noqa: E731
+        sk_t = cen(P.automorphism(big, [x % big for x in sk], t))
+        key = fhe.CkksKey(rns, *rns.ksk_gen(sk_d, dev(torch_cuda, np.array(sk_t, dtype=np.int64).view(np.uint64)), n, 53, t % 1000), n)
+        rb, ra = b[0:1].clone(), a[0:1].clone()
+        key.rotate_(t, rb, ra)
+        got = decrypt(qs, rows(rb[0]), rows(ra[0]))
+        want = cen(P.automorphism(big, [(delta * x) % big for x in ms[0]], t))
+        assert max(abs(g - w) for g, w in zip(got, want)) < 2 ** 18, t
