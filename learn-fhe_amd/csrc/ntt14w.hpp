@@ -99,6 +99,12 @@ __device__ unsigned long long g_stamps[4096][16];
 // pass 0 -> pass 1 (across waves; round h moves the coefficients with i[10] = h).  Pass-0 register (pass, n): n = the top R0 index
 // bits, pass = the 5 - R0 bits below them (i[10] first; R0 = 3: (i10, i9), R0 = 4: i10); thread t = the remaining low bits.
 // Slot of a coefficient in the half image (bit 10 removed): (n << 10) | i[9:0]; lanes keep i[5:0]: conflict free unpadded.
+#ifdef W14_LAB_NO_BARRIER  // developer lab only: what do the workgroup barriers of the cross-wave exchange cost? (results wrong)
+#define W14_SYNC() wave_sync()
+#else
+#define W14_SYNC() __syncthreads()
+#endif
+
 template <int R0>
 __device__ __forceinline__ void xchg_01(u64 (&x)[32], int t, int w, u64 *lds) {
     constexpr int PB = 5 - R0, NLOW = 1 << (PB - 1);  // register bits below bit 10 (i9 for R0 = 3, none for R0 = 4)
@@ -111,13 +117,13 @@ __device__ __forceinline__ void xchg_01(u64 (&x)[32], int t, int w, u64 *lds) {
         for (int lo = 0; lo < NLOW; ++lo)
 #pragma unroll
             for (int n = 0; n < (1 << R0); ++n) wp[(n << 10) | (lo << (10 - (PB - 1)))] = x[((((h << (PB - 1)) | lo)) << R0) | n];
-        __syncthreads();
+        W14_SYNC();
 #pragma unroll
         for (int m = 0; m < 16; ++m) {  // m = (i9 i8 i7 i6)
             const int n4 = (h << 3) | (m >> 1), s = m & 1;
             y[(s << 4) | n4] = rp[m << 6];
         }
-        __syncthreads();
+        W14_SYNC();
     }
     W14_PRIO_DOWN();
 #pragma unroll
@@ -130,7 +136,7 @@ __device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, int w, u64 *lds) {
     u64 *rp = lds + t, *wp = lds + (w << 10) + (t & 63);
     u64 y[32];
     W14_PRIO_UP();
-    __syncthreads();  // every wave has left its private region
+    W14_SYNC();  // every wave has left its private region
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -138,12 +144,12 @@ __device__ __forceinline__ void xchg_10(u64 (&x)[32], int t, int w, u64 *lds) {
             const int n4 = (h << 3) | (m >> 1), s = m & 1;
             wp[m << 6] = x[(s << 4) | n4];
         }
-        __syncthreads();
+        W14_SYNC();
 #pragma unroll
         for (int lo = 0; lo < NLOW; ++lo)
 #pragma unroll
             for (int n = 0; n < (1 << R0); ++n) y[((((h << (PB - 1)) | lo)) << R0) | n] = rp[(n << 10) | (lo << (10 - (PB - 1)))];
-        if (h == 0) __syncthreads();
+        if (h == 0) W14_SYNC();
     }
     W14_PRIO_DOWN();
 #pragma unroll

@@ -22,6 +22,13 @@ struct DSSkip : ArithDS<60> {  // ablation: the twiddles of the layers in M are 
     static constexpr unsigned SKIP_MASK = M;
     static __device__ __forceinline__ TwRaw fake(const K &k, int idx) { return uint4{k.ninv.x + (unsigned)idx, k.ninv.y, k.ninv.z ^ (unsigned)idx, k.ninv.w}; }
 };
+template <unsigned M>
+struct DSSkipV : ArithDS<60> {  // as DSSkip, but every word of a computed twiddle varies per lane (no scalar halves for the compiler to exploit)
+    static constexpr unsigned SKIP_MASK = M;
+    static __device__ __forceinline__ TwRaw fake(const K &k, int idx) {
+        return uint4{k.ninv.x + (unsigned)idx, (k.ninv.y ^ (unsigned)idx) & 0x7fffffffu, k.ninv.z ^ (unsigned)idx, (k.ninv.w + (unsigned)idx) & 0x7fffffffu};
+    }
+};
 struct DSNone : ArithDS<60> {  // ablation: HBM traffic + exchanges only
     static __device__ __forceinline__ void ct(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
     template <int PH> static __device__ __forceinline__ void gs(u64 &X, u64 &Y, const TwReg &, const K &) { X ^= 1; Y ^= 1; }
@@ -124,6 +131,9 @@ int main(int argc, char **argv) {
         {"DS60, pass-1 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x78>, false>, ntt14w_inv_kernel<DSSkip<0x78>, false>, 0, 0, 1},
         {"DS60, pass-0 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x7>, false>, ntt14w_inv_kernel<DSSkip<0x7>, false>, 0, 0, 1},
         {"DS60, pass-0/1 twiddles computed", ntt14w_fwd_kernel<DSSkip<0x7f>, false>, ntt14w_inv_kernel<DSSkip<0x7f>, false>, 0, 0, 1},
+        {"DS60, pass-3 tw computed per lane", ntt14w_fwd_kernel<DSSkipV<0x3800>, false>, ntt14w_inv_kernel<DSSkipV<0x3800>, false>, 0, 0, 1},
+        {"DS60, pass-2 tw computed per lane", ntt14w_fwd_kernel<DSSkipV<0x780>, false>, ntt14w_inv_kernel<DSSkipV<0x780>, false>, 0, 0, 1},
+        {"DS60, pass-2+3 tw computed per lane", ntt14w_fwd_kernel<DSSkipV<0x3f80>, false>, ntt14w_inv_kernel<DSSkipV<0x3f80>, false>, 0, 0, 1},
         {"wave-local, no butterflies", ntt14w_fwd_kernel<DSNone, false>, ntt14w_inv_kernel<DSNone, false>, 0, 0, 1},
     };
     std::vector<u64> ref(h.size()), got(h.size());
