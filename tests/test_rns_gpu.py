@@ -419,3 +419,40 @@ def test_ckks_device_keys_decrypt_level(fhe, torch_cuda):
         got = decrypt(qs, rows(rb[0]), rows(ra[0]))
         want = cen(P.automorphism(big, [(delta * x) % big for x in ms[0]], t))
         assert max(abs(g - w) for g, w in zip(got, want)) < 2 ** 18, t
+
+
+def test_ckks_ops_edge_cases(fhe, cref, torch_cuda):
+    """status codes where the reference would panic or has nothing to do: empty batches, a foreign key, a one-limb base, even t"""
+    import ctypes as C
+    lib = fhe.lib()
+    n = 64
+    primes = cref.two_adic_primes(50, 7, 5)
+    rns, other = fhe.RnsContext(primes[:2], primes[2:4]), fhe.RnsContext(primes[:2], primes[3:5])
+    one = fhe.RnsContext(primes[:1], primes[1:2])
+    kb, ka = rand_limbs(1, primes[:4], n), rand_limbs(2, primes[:4], n)
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    z = dev(torch_cuda, np.zeros((1, 2, n), dtype=np.uint64))
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    # batch 0: nothing to do
+    assert lib.fhe_ckks_mul(rns.handle, key._h, None, None, None, None, None, None, 0, 1, None) == 0
+    assert lib.fhe_ckks_rotate(rns.handle, key._h, 5, None, None, 0, 1, None) == 0
+    # a key prepared for another base (ckks.rs would hit the limb intersection / zip_eq panic)
+    assert lib.fhe_ckks_mul(other.handle, key._h, p(z), p(z), p(z), p(z), p(z), p(z), 1, 1, None) == 1
+    assert lib.fhe_ckks_rotate(other.handle, key._h, 5, p(z), p(z), 1, 1, None) == 1
+    # rescale() of a one-limb polynomial would leave nothing
+    assert lib.fhe_rns_rescale(one.handle, p(z), p(z), n, 1, 1, None) == 1
+    # even automorphism exponents are not permutations
+    with pytest.raises(fhe.FheError):
+        key.rotate_(6, z.clone(), z.clone())
+    # t is taken mod 2n: X -> X^(2n + 5) is X -> X^5
+    cb = dev(torch_cuda, rand_limbs(5, primes[:2], n, 1))
+    assert np.array_equal(host(rns.automorphism(cb, 2 * n + 5, n)), host(rns.automorphism(cb, 5, n)))
+    # n = 2 (the smallest ring the reference's tests use, ckks.rs:307 log_n = 1) through the whole multiplication
+    n2 = 2
+    small = fhe.RnsContext(primes[:2], primes[2:4])
+    k2b, k2a = rand_limbs(7, primes[:4], n2), rand_limbs(8, primes[:4], n2)
+    key2 = fhe.CkksKey(small, dev(torch_cuda, k2b), dev(torch_cuda, k2a), n2)
+    cts = [rand_limbs(9 + i, primes[:2], n2, 1) for i in range(4)]
+    ob, oa = key2.mul(*[dev(torch_cuda, c) for c in cts])
+    eb, ea = cref.ckks_mul(primes[:2], primes[2:4], k2b, k2a, *[c[0] for c in cts])
+    assert np.array_equal(host(ob)[0], eb) and np.array_equal(host(oa)[0], ea)
