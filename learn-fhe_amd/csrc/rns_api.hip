@@ -21,7 +21,8 @@ struct fhe_rns_ctx {
     void *d_blob = nullptr;            // all conversion tables
     fhe::BaseConv q2p{}, p2q{};
     fhe::RescaleConsts resc{};
-    fhe::RescaleConsts resc_last{};    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
+    fhe::RescaleConsts resc_last{};
+    bool ds = false;                   // every modulus is a 60-bit pseudo-Mersenne prime: conversions on the two-operand products    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
     int max_log_n = 0;                 // largest ring degree every prime supports
     int all_pm = -1;                   // common pseudo-Mersenne bit length of all primes, 0 if none
 };
@@ -58,7 +59,14 @@ struct BlobBuilder {
     }
 };
 
-struct ConvOffsets { size_t a_mod, ahat_inv, ahat_inv_s, frac, b_mod, c, c_s, ua; int la, lb; };
+struct ConvOffsets { size_t a_mod, ahat_inv, ahat_inv_s, frac, b_mod, c, c_s, ua, inv_ds, c_ds, a_c, b_c; int la, lb; };
+
+// {a0, a1, b0, b1} of ArithDS<60> as two blob words; w < q < 2^60
+void put_ds(std::vector<uint64_t> &out, uint64_t w, uint64_t q) {
+    const uint4 d = fhe::ArithDS<60>::split(w, q);
+    out.push_back((uint64_t)d.x | ((uint64_t)d.y << 32));
+    out.push_back((uint64_t)d.z | ((uint64_t)d.w << 32));
+}
 
 ConvOffsets build_conv(BlobBuilder &bb, const std::vector<uint64_t> &A, const std::vector<uint64_t> &B) {
     const int la = (int)A.size(), lb = (int)B.size();
@@ -81,6 +89,19 @@ ConvOffsets build_conv(BlobBuilder &bb, const std::vector<uint64_t> &A, const st
     o.la = la; o.lb = lb;
     o.a_mod = bb.put(A); o.ahat_inv = bb.put(inv); o.ahat_inv_s = bb.put(inv_s); o.frac = bb.put_f64(frac);
     o.b_mod = bb.put(B); o.c = bb.put(c); o.c_s = bb.put(c_s); o.ua = bb.put(ua);
+    // two-operand forms (read only when the context's `ds` flag is set; harmless otherwise)
+    std::vector<uint64_t> inv_ds, c_ds, a_c, b_c;
+    for (int i = 0; i < la; ++i) put_ds(inv_ds, inv[i], A[i]);
+    for (int j = 0; j < lb; ++j)
+        for (int i = 0; i < la; ++i) put_ds(c_ds, c[size_t(j) * la + i], B[j]);
+    // 32-bit c values packed two per word
+    auto pack_c = [](const std::vector<uint64_t> &M) {
+        std::vector<uint64_t> w((M.size() + 1) / 2, 0);
+        for (size_t i = 0; i < M.size(); ++i) w[i / 2] |= (uint64_t)(uint32_t)((uint64_t(1) << 60) - M[i]) << (32 * (i & 1));
+        return w;
+    };
+    if (bb.words.size() & 1) bb.words.push_back(0);  // 16-byte alignment of the uint4 tables
+    o.inv_ds = bb.put(inv_ds); o.c_ds = bb.put(c_ds); o.a_c = bb.put(pack_c(A)); o.b_c = bb.put(pack_c(B));
     return o;
 }
 
@@ -90,6 +111,8 @@ fhe::BaseConv conv_view(const ConvOffsets &o, const uint64_t *base) {
     C.a_mod = (const u64 *)base + o.a_mod; C.ahat_inv = (const u64 *)base + o.ahat_inv; C.ahat_inv_s = (const u64 *)base + o.ahat_inv_s;
     C.frac = (const double *)(base + o.frac);
     C.b_mod = (const u64 *)base + o.b_mod; C.c = (const u64 *)base + o.c; C.c_s = (const u64 *)base + o.c_s; C.ua = (const u64 *)base + o.ua;
+    C.ahat_inv_ds = (const uint4 *)(base + o.inv_ds); C.c_ds = (const uint4 *)(base + o.c_ds);
+    C.a_c = (const unsigned *)(base + o.a_c); C.b_c = (const unsigned *)(base + o.b_c);
     return C;
 }
 
@@ -154,6 +177,10 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     }
     for (int j = 0; j < K; ++j) half_p[j] = half_of_p(ps[j]);
     const size_t o_hq = bb.put(half_q), o_hp = bb.put(half_p), o_pi = bb.put(pinv), o_pis = bb.put(pinv_s), o_mu = bb.put(red_mu);
+    std::vector<uint64_t> pinv_ds;
+    for (int i = 0; i < L; ++i) put_ds(pinv_ds, pinv[i], qs[i]);
+    if (bb.words.size() & 1) bb.words.push_back(0);
+    const size_t o_pids = bb.put(pinv_ds);
     // rns.rs:99-101 `rescale()`: the same formulas with P = the last q-limb (rns.rs:104-111, the K == 1 branch)
     std::vector<uint64_t> lhalf_q(L), lhalf_p(1), lpinv(L), lpinv_s(L);
     if (L >= 2) {
@@ -166,6 +193,10 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
         }
     }
     const size_t o_lhq = bb.put(lhalf_q), o_lhp = bb.put(lhalf_p), o_lpi = bb.put(lpinv), o_lpis = bb.put(lpinv_s);
+    std::vector<uint64_t> lpinv_ds;
+    for (int i = 0; i < L; ++i) put_ds(lpinv_ds, lpinv[i], qs[i]);
+    if (bb.words.size() & 1) bb.words.push_back(0);
+    const size_t o_lpids = bb.put(lpinv_ds);
     std::vector<fhe::ModDesc> descs(L + K);
     std::vector<fhe::Barrett> bar(L + K);
     for (int i = 0; i < L + K; ++i) { descs[i] = r->mods[i]->h_desc; bar[i] = r->mods[i]->barrett; }
@@ -184,12 +215,15 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     r->resc.half_q = (const u64 *)base + o_hq; r->resc.half_p = (const u64 *)base + o_hp;
     r->resc.pinv = (const u64 *)base + o_pi; r->resc.pinv_s = (const u64 *)base + o_pis;
     r->resc.red_mu = (const u64 *)base + o_mu;
+    r->resc.pinv_ds = (const uint4 *)(base + o_pids);
     r->resc.p2q = r->p2q;
+    r->ds = r->all_pm == 60;
     r->resc_last = r->resc;  // p2q unused when K == 1
     r->resc_last.L = L - 1; r->resc_last.K = 1;
     r->resc_last.p_mod = r->q2p.a_mod + (L - 1);
     r->resc_last.half_q = (const u64 *)base + o_lhq; r->resc_last.half_p = (const u64 *)base + o_lhp;
     r->resc_last.pinv = (const u64 *)base + o_lpi; r->resc_last.pinv_s = (const u64 *)base + o_lpis;
+    r->resc_last.pinv_ds = (const uint4 *)(base + o_lpids);
     *out = r;
     return FHE_OK;
 }
@@ -212,14 +246,16 @@ struct PointwiseGrid {
         g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
     }
 };
-void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C)
+void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, bool ds, hipStream_t st) {
+#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C); \
+                        else hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C); } while (0)
     RNS_BOUND(C.la, CALL);
 #undef CALL
 }
 void launch_rescale(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
-                    const fhe::RescaleConsts &R, hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
+                    const fhe::RescaleConsts &R, bool ds, hipStream_t st) {
+#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R); \
+                        else hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R); } while (0)
     RNS_BOUND(R.K, CALL);
 #undef CALL
 }
@@ -234,7 +270,7 @@ int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror mi(in, n * batch * r->L, mem, true, st), mo(out, n * batch * r->K, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_extend(mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, r->q2p, st);
+    launch_extend(mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, r->q2p, r->ds, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -249,7 +285,7 @@ int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, s
     const size_t lk = size_t(r->L + r->K);
     Mirror mi(in, n * batch * lk, mem, true, st), mo(out, n * batch * r->L, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, r->resc, st);
+    launch_rescale(mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, r->resc, r->ds, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -355,7 +391,7 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
     // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps)
     if (hipMemcpy2DAsync(ext, lk * n * 8, a_in, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK) {
-        launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, st);
+        launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, r->ds, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
@@ -372,8 +408,8 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) {
-        launch_rescale(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, st);
-        launch_rescale(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, st);
+        launch_rescale(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, r->ds, st);
+        launch_rescale(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, r->ds, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     return rc;
@@ -410,7 +446,7 @@ int fhe_rns_rescale(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, siz
     const size_t L = r->L;
     Mirror mi(in, n * batch * L, mem, true, st), mo(out, n * batch * (L - 1), mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
+    launch_rescale(mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -506,8 +542,8 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
     // (d0, d1) + relinearize(d2) (ckks.rs:262, 265-272): the key switch adds d0 and d1 as it rescales; its outputs reuse e
     if (rc == FHE_OK) rc = key_switch_dev(r, rlk, d + 2 * words, d, d + words, e, e + words, batch, st);
     if (rc == FHE_OK) {
-        launch_rescale(e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
-        launch_rescale(e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, st);
+        launch_rescale(e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
+        launch_rescale(e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) rc = mob.sync_out(st);

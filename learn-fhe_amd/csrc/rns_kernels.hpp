@@ -3,6 +3,7 @@
 // Ckks::key_switch (scheme/ckks/src/ckks.rs:284-293).  One thread per coefficient; limb-major polynomials.
 #pragma once
 #include "dev_arith.hpp"
+#include "arith.hpp"
 
 namespace fhe {
 
@@ -28,21 +29,34 @@ struct BaseConv {
     const u64 *c;           // [lb][la]  (A / a_i) mod b_j          (rns.rs:305-313 q_hats_ps)
     const u64 *c_s;         // [lb][la]  Shoup companions
     const u64 *ua;          // [lb][la + 1]  (u * A) mod b_j         (rns.rs:315-320 uq_ps)
+    // the same constants in the two-operand form of ArithDS<60> (arith.hpp), present when every modulus of both bases is a 60-bit
+    // pseudo-Mersenne prime (all of CkksParam's): a product is 6 multiply-adds + a 3-instruction fold instead of the ~14 of a lazy
+    // Shoup product -- the conversions are bound by exactly these products (80 per coefficient at cfg4)
+    const uint4 *ahat_inv_ds;  // [la]
+    const uint4 *c_ds;         // [lb][la]
+    const unsigned *a_c, *b_c; // [la], [lb]  2^60 - modulus
 };
+
+__device__ __forceinline__ DsK rns_dsk(u64 q, unsigned c) { return DsK{q, 2 * q, 4 * q, c, 2 * c, 1u << 29}; }
+__device__ __forceinline__ uint4 ldc4(const uint4 *p, int i) {
+    const __attribute__((address_space(4))) uint4 *q = (const __attribute__((address_space(4))) uint4 *)p + i;
+    return uint4{q->x, q->y, q->z, q->w};
+}
 
 // The per-coefficient limb vectors live in REGISTERS: every loop over source limbs is unrolled to the compile-time bound MAXA
 // (4 / 8 / 16 / 32, the smallest that holds the base) and predicated on the run-time count -- a run-time trip count would
 // put v[] / vs[] in scratch memory (measured: 57 us -> see DESIGN.md 4.5 for the cfg4 rescale).
 //
 // vs_i = v_i * ahat_inv_i mod a_i; u = round(sum_i frac_i * vs_i) with the reference's sequential f64 sum
-template <int MAXA, bool FULL>
+template <int MAXA, bool FULL, bool DS = false>
 __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&v)[MAXA], u64 (&vs)[MAXA]) {
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
         if (FULL || i < C.la) {
             const u64 a = ldc(C.a_mod, i);
-            vs[i] = csub(mul_shoup_lazy(v[i], ldc(C.ahat_inv, i), ldc(C.ahat_inv_s, i), a), a);
+            if constexpr (DS) vs[i] = csub(ArithDS<60>::mul(v[i], ldc4(C.ahat_inv_ds, i), rns_dsk(a, ldc(C.a_c, i))), a);  // < q + 9c -> canonical
+            else vs[i] = csub(mul_shoup_lazy(v[i], ldc(C.ahat_inv, i), ldc(C.ahat_inv_s, i), a), a);
             acc = __dadd_rn(acc, __dmul_rn(ldc(C.frac, i), (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
         } else {
             vs[i] = 0;
@@ -52,21 +66,31 @@ __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&
 }
 
 // sum_i c_ji * vs_i - ua_j[u]  (mod b_j), canonical
-template <int MAXA, bool FULL>
+template <int MAXA, bool FULL, bool DS = false>
 __device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 (&vs)[MAXA], int u) {
     const int la = FULL ? MAXA : C.la;  // FULL: the source base has exactly MAXA limbs -- no predicate, constant strides
     const u64 b = ldc(C.b_mod, j), b2 = 2 * b;
     u64 dot = 0;
+    if constexpr (DS) {
+        const DsK m = rns_dsk(b, ldc(C.b_c, j));
 #pragma unroll
-    for (int i = 0; i < MAXA; ++i)
-        if (FULL || i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], ldc(C.c, j * la + i), ldc(C.c_s, j * la + i), b), b2);
-    dot = csub(dot, b);
+        for (int i = 0; i < MAXA; ++i) {
+            if (FULL || i < C.la) dot += ArithDS<60>::mul(vs[i], ldc4(C.c_ds, j * la + i), m);  // each < q + 9c: eight of them fit 2^63
+            if ((i & 7) == 7 && i + 1 < MAXA) dot = ArithDS<60>::fold1(dot, m);
+        }
+        dot = csub(ArithDS<60>::fold1(dot, m), b);  // < 2^60 + 9c < 2q
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXA; ++i)
+            if (FULL || i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], ldc(C.c, j * la + i), ldc(C.c_s, j * la + i), b), b2);
+        dot = csub(dot, b);
+    }
     const u64 sub = C.ua[j * (la + 1) + u];  // (u differs per lane: a vector load)
     return dot >= sub ? dot - sub : dot + b - sub;
 }
 
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
-template <int MAXA, bool FULL>
+template <int MAXA, bool FULL, bool DS = false>
 __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
                                   BaseConv C) {
     const size_t total = n * batch;
@@ -75,13 +99,13 @@ __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 
         u64 v[MAXA], vs[MAXA];
 #pragma unroll
         for (int l = 0; l < MAXA; ++l) v[l] = (FULL || l < C.la) ? in[p * in_bs + size_t(l) * n + i] : 0;
-        const int u = base_conv_prepare<MAXA, FULL>(C, v, vs);
+        const int u = base_conv_prepare<MAXA, FULL, DS>(C, v, vs);
         // output limbs in independent chains of up to MAXA at a time (the bound that serves the source base serves the target
         // base of the BASELINE shapes too): the unrolled bodies give the scheduler eight dot products to interleave
         for (int j0 = 0; j0 < C.lb; j0 += MAXA) {
 #pragma unroll
             for (int jj = 0; jj < MAXA; ++jj)
-                if (j0 + jj < C.lb) out[p * out_bs + size_t(j0 + jj) * n + i] = base_conv_out<MAXA, FULL>(C, j0 + jj, vs, u);
+                if (j0 + jj < C.lb) out[p * out_bs + size_t(j0 + jj) * n + i] = base_conv_out<MAXA, FULL, DS>(C, j0 + jj, vs, u);
         }
     }
 }
@@ -92,12 +116,13 @@ struct RescaleConsts {
     const u64 *half_q, *half_p;        // floor(P/2) mod q_i, mod p_j        (rns.rs:120-125 `round`)
     const u64 *pinv, *pinv_s;          // P^-1 mod q_i + Shoup               (rns.rs:127-132 `div`)
     const u64 *red_mu;                 // [L] floor(2^64 / q_i): 64-bit Barrett for `vp % q_i` in the K == 1 path
+    const uint4 *pinv_ds;              // [L] P^-1 mod q_i in the two-operand form (with p2q.*_ds)
     BaseConv p2q;                      // switch_bases P -> Q                (rns.rs:93-97)
 };
 
 // util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
-template <int MAXA, bool FULL>
+template <int MAXA, bool FULL, bool DS = false>
 __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs,
                                    const u64 *addend, size_t add_bs, size_t n, size_t batch, RescaleConsts R) {
     const size_t total = n * batch;
@@ -107,7 +132,7 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
 #pragma unroll
         for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < R.K) ? csub(in[p * in_bs + size_t(R.L + j) * n + i] + ldc(R.half_p, j), ldc(R.p_mod, j)) : 0;
         int u = 0;
-        if (R.K > 1) u = base_conv_prepare<MAXA, FULL>(R.p2q, vp, vs);
+        if (R.K > 1) u = base_conv_prepare<MAXA, FULL, DS>(R.p2q, vp, vs);
         for (int l0 = 0; l0 < R.L; l0 += MAXA) {
 #pragma unroll
           for (int ll = 0; ll < MAXA; ++ll) {
@@ -121,10 +146,12 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
                 sw = x - __umul64hi(x, ldc(R.red_mu, l)) * q;
                 sw = csub(csub(sw, q), q);
             } else {
-                sw = base_conv_out<MAXA, FULL>(R.p2q, l, vs, u);
+                sw = base_conv_out<MAXA, FULL, DS>(R.p2q, l, vs, u);
             }
             const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
-            u64 r = csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
+            u64 r;
+            if constexpr (DS) r = csub(ArithDS<60>::mul(diff, ldc4(R.pinv_ds, l), rns_dsk(q, ldc(R.p2q.b_c, l))), q);
+            else r = csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
             if (addend) r = csub(r + addend[p * add_bs + size_t(l) * n + i], q);
             out[p * out_bs + size_t(l) * n + i] = r;
           }
