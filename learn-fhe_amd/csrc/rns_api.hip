@@ -246,9 +246,10 @@ struct PointwiseGrid {
         g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
     }
 };
-void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, bool ds, hipStream_t st) {
-#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C); \
-                        else hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C); } while (0)
+void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, bool ds, hipStream_t st,
+                   u64 *copy = nullptr, size_t copy_bs = 0) {
+#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs); \
+                        else hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs); } while (0)
     RNS_BOUND(C.la, CALL);
 #undef CALL
 }
@@ -388,12 +389,9 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
     u64 *ws = wsp.as<u64>();
     u64 *ext = ws, *pb = ws + blk;
     int rc = FHE_OK;
-    // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps)
-    if (hipMemcpy2DAsync(ext, lk * n * 8, a_in, L * n * 8, L * n * 8, batch, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
-    if (rc == FHE_OK) {
-        launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, r->ds, st);
-        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
-    }
+    // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps): one kernel, the q-limbs written back out of the registers it read them into
+    launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, r->ds, st, ext, lk * n);
+    if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
     // ksk.b * a~ and ksk.a * a~ (ring/rns.rs:148-158) ride on the load of ONE inverse launch over the 2 * batch * lk output
     // limbs: output limb s reads a~ limb s % (batch lk) and key limb (s / (batch lk)) lk + s % lk (d_kb and d_ka are adjacent)

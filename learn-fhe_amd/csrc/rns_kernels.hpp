@@ -92,13 +92,18 @@ __device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][lb][n] (stride out_bs)
 template <int MAXA, bool FULL, bool DS = false>
 __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
-                                  BaseConv C) {
+                                  BaseConv C, u64 *__restrict__ copy, size_t copy_bs) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
         u64 v[MAXA], vs[MAXA];
 #pragma unroll
         for (int l = 0; l < MAXA; ++l) v[l] = (FULL || l < C.la) ? in[p * in_bs + size_t(l) * n + i] : 0;
+        if (copy) {  // the key switch wants the source limbs next to the new ones ([batch][la + lb][n]): they are in registers already
+#pragma unroll
+            for (int l = 0; l < MAXA; ++l)
+                if (FULL || l < C.la) copy[p * copy_bs + size_t(l) * n + i] = v[l];
+        }
         const int u = base_conv_prepare<MAXA, FULL, DS>(C, v, vs);
         // output limbs in independent chains of up to MAXA at a time (the bound that serves the source base serves the target
         // base of the BASELINE shapes too): the unrolled bodies give the scheduler eight dot products to interleave
