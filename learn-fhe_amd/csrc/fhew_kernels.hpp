@@ -219,17 +219,28 @@ struct RingConsts {
     Barrett B;            // variable x variable products of the multiply-accumulate
 };
 
+// One key row (a and b components of one limb) as a lane holds it: E / 2 16-byte loads each.  The row of limb j + 1 is requested
+// as soon as the multiply-accumulate of limb j has consumed its registers, so the fetch (the bootstrapping keys exceed the L2:
+// rows come from the Infinity Cache) flies under the next limb's decomposition and forward transform instead of stalling the
+// wave in front of every multiply-accumulate (44 % of the wave cycles of a blind rotation were parked in s_waitcnt).
+template <class W>
+struct KeyRow {
+    ulonglong2 a[W::E / 2], b[W::E / 2];
+};
+template <class W>
+__device__ __forceinline__ void load_row(KeyRow<W> &kr, const u64 *__restrict__ row, int lane) {
+    const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
+    const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + (1 << W::LOG_N));
+#pragma unroll
+    for (int r2 = 0; r2 < W::E / 2; ++r2) { kr.a[r2] = ka[r2 * W::TEAM + lane]; kr.b[r2] = kb[r2 * W::TEAM + lane]; }
+}
 // sums[0][r] += x[r] * keyA[r], sums[1][r] += x[r] * keyB[r]  for one limb; x arrives lazy in [0, 4q)
 template <class A, class W>
-__device__ __forceinline__ void mac_row(const u64 (&x)[W::E], typename A::MacAcc (&sa)[W::E],
-                                        typename A::MacAcc (&sb)[W::E],
-                                        const u64 *__restrict__ row, int lane, int term, const RingConsts &K, const typename A::K &k) {
-    constexpr int E = W::E, N = 1 << W::LOG_N, TEAM = W::TEAM;
-    const ulonglong2 *ka = reinterpret_cast<const ulonglong2 *>(row);
-    const ulonglong2 *kb = reinterpret_cast<const ulonglong2 *>(row + N);
+__device__ __forceinline__ void mac_row(const u64 (&x)[W::E], typename A::MacAcc (&sa)[W::E], typename A::MacAcc (&sb)[W::E],
+                                        const KeyRow<W> &kr, int term, const RingConsts &K, const typename A::K &k) {
 #pragma unroll
-    for (int r2 = 0; r2 < E / 2; ++r2) {
-        const ulonglong2 a = ka[r2 * TEAM + lane], b = kb[r2 * TEAM + lane];
+    for (int r2 = 0; r2 < W::E / 2; ++r2) {
+        const ulonglong2 a = kr.a[r2], b = kr.b[r2];
         const u64 x0 = A::mac_in(x[2 * r2], k), x1 = A::mac_in(x[2 * r2 + 1], k);
         sa[2 * r2] = A::mac(sa[2 * r2], x0, a.x, term, k, K.B);
         sa[2 * r2 + 1] = A::mac(sa[2 * r2 + 1], x1, a.y, term, k, K.B);
@@ -255,6 +266,8 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W
 #pragma unroll
     for (int e = 0; e < E; ++e) { ma[e] = mb[e] = A::mac_zero(); st[e] = decomp_init(ca[e], P); }
     const int total = both ? 2 * P.d : P.d;
+    KeyRow<W> kr;
+    load_row<W>(kr, rows, lane);
 #pragma unroll 1
     for (int j = 0; j < total; ++j) {
         if (both && j == P.d) {
@@ -265,7 +278,8 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W
 #pragma unroll
         for (int e = 0; e < E; ++e) x[e] = decomp_next(st[e], P);
         fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, W>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        mac_row<A, W>(x, ma, mb, kr, j, K, k);
+        if (j + 1 < total) load_row<W>(kr, rows + size_t(j + 1) * 2 * W::N, lane);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }

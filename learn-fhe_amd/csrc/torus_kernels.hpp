@@ -91,6 +91,8 @@ __device__ __forceinline__ void team_torus_gadget(const u64 (&da)[W::E], const u
     u64 st[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { ma[e] = mb[e] = A::mac_zero(); st[e] = tdecomp_init(da[e], P); }
+    KeyRow<W> kr;  // one limb ahead (fhew_kernels.hpp)
+    load_row<W>(kr, rows, lane);
 #pragma unroll 1
     for (int j = 0; j < 2 * P.d; ++j) {
         if (j == P.d) {
@@ -104,7 +106,8 @@ __device__ __forceinline__ void team_torus_gadget(const u64 (&da)[W::E], const u
             x[e] = (long long)dg < 0 ? p - (0 - dg) : dg;  // |digit| <= 2^(log_b-1) < p
         }
         fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row<A, W>(x, ma, mb, rows + size_t(j) * 2 * W::N, lane, j, K, k);
+        mac_row<A, W>(x, ma, mb, kr, j, K, k);
+        if (j + 1 < 2 * P.d) load_row<W>(kr, rows + size_t(j + 1) * 2 * W::N, lane);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = A::mac_finish(ma[e], k); sb[e] = A::mac_finish(mb[e], k); }
