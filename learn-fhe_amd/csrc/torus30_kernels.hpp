@@ -38,15 +38,25 @@ __host__ __device__ __forceinline__ int key_perm30(int e) {
     return (r >> 2) * (4 * W::TEAM) + lane * 4 + (r & 3);
 }
 
+// one key row (a and b of one limb) as a lane holds it; fetched one limb ahead of its multiply-accumulate (fhew_kernels.hpp: KeyRow)
 template <class W>
-__device__ __forceinline__ void mac_row30(const unsigned (&x)[W::E], unsigned (&sa)[W::E], unsigned (&sb)[W::E], const unsigned *__restrict__ row,
-                                          int lane, const Arith30::K &k) {
+struct KeyRow30 {
+    uint4 a[W::E / 4], b[W::E / 4];
+};
+template <class W>
+__device__ __forceinline__ void load_row30(KeyRow30<W> &kr, const unsigned *__restrict__ row, int lane) {
     static_assert(W::E % 4 == 0, "16-byte key loads");
     const uint4 *ka = reinterpret_cast<const uint4 *>(row);
     const uint4 *kb = reinterpret_cast<const uint4 *>(row + W::N);
 #pragma unroll
+    for (int r4 = 0; r4 < W::E / 4; ++r4) { kr.a[r4] = ka[r4 * W::TEAM + lane]; kr.b[r4] = kb[r4 * W::TEAM + lane]; }
+}
+template <class W>
+__device__ __forceinline__ void mac_row30(const unsigned (&x)[W::E], unsigned (&sa)[W::E], unsigned (&sb)[W::E], const KeyRow30<W> &kr,
+                                          const Arith30::K &k) {
+#pragma unroll
     for (int r4 = 0; r4 < W::E / 4; ++r4) {
-        const uint4 a = ka[r4 * W::TEAM + lane], b = kb[r4 * W::TEAM + lane];
+        const uint4 a = kr.a[r4], b = kr.b[r4];
         sa[4 * r4 + 0] = Arith30::mac(sa[4 * r4 + 0], x[4 * r4 + 0], a.x, k);
         sa[4 * r4 + 1] = Arith30::mac(sa[4 * r4 + 1], x[4 * r4 + 1], a.y, k);
         sa[4 * r4 + 2] = Arith30::mac(sa[4 * r4 + 2], x[4 * r4 + 2], a.z, k);
@@ -68,6 +78,8 @@ __device__ __forceinline__ void team_torus_gadget30(const u64 (&da)[W::E], const
     u64 st[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { sa[e] = sb[e] = 0; st[e] = tdecomp_init(da[e], P); }
+    KeyRow30<W> kr;
+    load_row30<W>(kr, rows, lane);
 #pragma unroll 1
     for (int j = 0; j < 2 * P.d; ++j) {
         if (j == P.d) {
@@ -81,7 +93,8 @@ __device__ __forceinline__ void team_torus_gadget30(const u64 (&da)[W::E], const
             x[e] = dg < 0 ? k.p + (unsigned)dg : (unsigned)dg;
         }
         fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
-        mac_row30<W>(x, sa, sb, rows + size_t(j) * 2 * W::N, lane, k);
+        mac_row30<W>(x, sa, sb, kr, k);
+        if (j + 1 < 2 * P.d) load_row30<W>(kr, rows + size_t(j + 1) * 2 * W::N, lane);
     }
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
