@@ -17,25 +17,10 @@ inline unsigned grid_for(size_t total) {
     return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
 }
 
-// distribution.rs:25-45, evaluated on the host exactly as the reference does
-int make_dg_table(double std_dev, int n_sigma, fhe::DgTable *T) {
+// distribution.rs:25-45 (keygen_kernels.hpp: fhe::make_dg_table) with the entry points' status codes
+int dg_table_rc(double std_dev, int n_sigma, fhe::DgTable *T) {
     if (!(std_dev > 0) || n_sigma < 1) return FHE_ERR_INVALID;
-    auto erf_as = [](double x) {
-        const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
-        const double t = 1.0 / (1.0 + p * std::fabs(x));
-        const double pos = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
-        return std::signbit(x) ? -pos : pos;
-    };
-    auto cdf = [&](double x) { return (1.0 + erf_as(x / (std_dev * 1.4142135623730951))) / 2.0; };
-    const long long mx = (long long)std::floor((double)n_sigma * std_dev);
-    if (mx < 0 || 2 * mx + 1 > fhe::DG_MAX_TABLE) return FHE_ERR_UNSUPPORTED;
-    T->max = (int)mx; T->len = (int)(2 * mx + 1);
-    double acc = 0;
-    for (long long i = -mx; i <= mx; ++i) {
-        acc += cdf((double)i + 0.5) - cdf((double)i - 0.5);
-        T->cum[i + mx] = acc;
-    }
-    return FHE_OK;
+    return fhe::make_dg_table(std_dev, n_sigma, T) ? FHE_OK : FHE_ERR_UNSUPPORTED;
 }
 
 // blocks of the generator a draw of `count` values occupies: callers advance `first` by this to chain independent draws on one stream id
@@ -58,7 +43,7 @@ int rlwe_sk_encrypt_dev(const fhe_ctx *ctx, const u64 *sk_eval, const u64 *pt, s
     const size_t count = rows * n;
     const int log_n = ilog2(n);
     fhe::DgTable T;
-    int rc = make_dg_table(3.2, 6, &T);
+    int rc = dg_table_rc(3.2, 6, &T);
     if (rc != FHE_OK) return rc;
     StreamWs we(count * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;
@@ -135,7 +120,7 @@ int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64
                   void *stream) {
     if ((q >> 62) || q == 1 || (!out && count)) return FHE_ERR_INVALID;
     fhe::DgTable T;
-    int rc = make_dg_table(std_dev, n_sigma, &T);
+    int rc = dg_table_rc(std_dev, n_sigma, &T);
     if (rc != FHE_OK) return rc;
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -260,7 +245,7 @@ int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, 
 static int lwe_encrypt_common(uint64_t q, const u64 *sk, const u64 *pt, const u64 *sk1, size_t n1, int rb, int log_b, size_t n, size_t rows,
                               uint64_t seed, uint64_t stream_id, u64 *out_a, u64 *out_b, hipStream_t st) {
     fhe::DgTable T;
-    int rc = make_dg_table(3.2, 6, &T);
+    int rc = dg_table_rc(3.2, 6, &T);
     if (rc != FHE_OK) return rc;
     StreamWs we(rows * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;

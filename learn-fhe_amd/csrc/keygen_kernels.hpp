@@ -7,6 +7,7 @@
 // 64-bit block counter): reproducible, order independent, and a CSPRNG as the reference's generator is.  Draws are NOT
 // parity-relevant (the reference's are unseeded): these producers are validated at decrypt level and statistically.
 #pragma once
+#include <cmath>
 #include "arith.hpp"
 
 namespace fhe {
@@ -85,6 +86,25 @@ struct DgTable {
     double cum[DG_MAX_TABLE];
     int len, max;
 };
+// the table itself, evaluated on the host exactly as the reference does (distribution.rs:25-45); false: unsupported shape
+inline bool make_dg_table(double std_dev, int n_sigma, DgTable *T) {
+    auto erf_as = [](double x) {
+        const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
+        const double t = 1.0 / (1.0 + p * std::fabs(x));
+        const double pos = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+        return std::signbit(x) ? -pos : pos;
+    };
+    auto cdf = [&](double x) { return (1.0 + erf_as(x / (std_dev * 1.4142135623730951))) / 2.0; };
+    const long long mx = (long long)std::floor((double)n_sigma * std_dev);
+    if (mx < 0 || 2 * mx + 1 > DG_MAX_TABLE) return false;
+    T->max = (int)mx; T->len = (int)(2 * mx + 1);
+    double acc = 0;
+    for (long long i = -mx; i <= mx; ++i) {
+        acc += cdf((double)i + 0.5) - cdf((double)i - 0.5);
+        T->cum[i + mx] = acc;
+    }
+    return true;
+}
 FHE_HEADER_KERNEL void sample_dg_kernel(u64 *__restrict__ out, size_t count, u64 q, DgTable T, ChaChaKey K, unsigned long long first) {
     for (size_t blk = blockIdx.x * size_t(blockDim.x) + threadIdx.x; blk * 8 < count; blk += size_t(gridDim.x) * blockDim.x) {
         unsigned long long w[8];

@@ -552,23 +552,6 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
 // ---- CKKS key material on the device (scheme/ckks/src/ckks.rs:139-183, 215-225) ---------------------------------------------
 }  // extern "C"
 namespace {
-// distribution.rs:25-45 `dg(3.2, 6)` cumulative weights, as in keygen_api.hip
-int ckks_dg_table(fhe::DgTable *T) {
-    const double std_dev = 3.2;
-    auto erf_as = [](double x) {
-        const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
-        const double t = 1.0 / (1.0 + p * std::fabs(x));
-        const double pos = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
-        return std::signbit(x) ? -pos : pos;
-    };
-    auto cdf = [&](double x) { return (1.0 + erf_as(x / (std_dev * 1.4142135623730951))) / 2.0; };
-    const long long mx = (long long)std::floor(6.0 * std_dev);
-    T->max = (int)mx; T->len = (int)(2 * mx + 1);
-    double acc = 0;
-    for (long long i = -mx; i <= mx; ++i) { acc += cdf((double)i + 0.5) - cdf((double)i - 0.5); T->cum[i + mx] = acc; }
-    return FHE_OK;
-}
-
 // ckks.rs:215-225 on device buffers over the first `limbs` moduli of qs ++ ps: a uniform, e <- dg(3.2, 6), b = -(a s) + e + pt.
 // sk [n] two's-complement i64; pt [pt_batch][limbs][n] or null; out_b, out_a [batch][limbs][n]
 int ckks_sk_encrypt_dev(const fhe_rns_ctx *r, int limbs, const u64 *sk, const u64 *pt, size_t pt_batch, u64 *out_b, u64 *out_a, int log_n,
@@ -590,7 +573,7 @@ int ckks_sk_encrypt_dev(const fhe_rns_ctx *r, int limbs, const u64 *sk, const u6
             if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
         }
     fhe::DgTable T;
-    ckks_dg_table(&T);
+    (void)fhe::make_dg_table(3.2, 6, &T);  // dg(3.2, 6): 39 entries
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::sample_dg_kernel, dim3(grid_for((batch * n + 7) / 8)), dim3(256), 0, st, e, batch * n, (u64)0, T, K, *cursor);
         *cursor += (batch * n + 7) / 8;
