@@ -473,7 +473,10 @@ def main():
 
     sharded = None
     if dist is not None and not args.no_fhew:
-        sharded = sharded_secondary(torch, F, dist, dev, local_rank, rank, world, args.dist_backend)
+        try:  # extras: a failure here (the same code runs on every rank, so it fails on every rank) must not cost the headline line
+            sharded = sharded_secondary(torch, F, dist, dev, local_rank, rank, world, args.dist_backend)
+        except Exception as e:  # noqa: BLE001
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         transforms = 2.0 * total * args.steps
