@@ -499,7 +499,7 @@ def main():
                          "kernel, FETCH_SIZE x2 + WRITE_SIZE; not re-measured by this process)" if pmc.get("ntt_fwd_bytes_per_launch") else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
                          "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
-                         "inv_kernel": "ntt14w_inv_kernel<ArithPM<60>, false>",
+                         "inv_kernel": "ntt14w_inv_kernel<ArithDS<60>, false>",
                          "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9,
                          "inv_frac": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "secondary_bound": "VALU issue (64-bit modular butterflies on 32-bit multipliers): see DESIGN.md 4.3; "

@@ -60,6 +60,12 @@ struct ModDesc {
     // ... of (2^k)^-1, of (2^k)^-1 twi[1] and of 1: split on the host -- the w 2^32 mod q half is a 128-bit remainder, which a
     // kernel that formed it itself paid for in every workgroup (0.045 ms of a 0.33 ms launch of 4096 inverse transforms)
     uint4 ds_ninv[20], ds_ninv_w[20], ds_one;
+    // Diagonal form of the inverse's first three layers (ntt14w.hpp, pass 3): within a block of 8 coefficients the three
+    // Gentleman-Sande layers equal a fixed 8-point network (twiddles twi[1], twi[2], twi[3] only) followed by the diagonal
+    // (1, t, t^2, .., t^7), t = twi[4 blk] the block's first last-layer twiddle.  twd3i[(p - 1) * twd3_stride + blk] = t^p in the
+    // two-operand form, p = 1..7, blk < twd3_stride = cap / 4: valid for every ring size and sub-transform prefix like twi itself.
+    const uint4 *twd3i;
+    unsigned twd3_stride;
     // classical Barrett constants (dev_arith.hpp) for products of two VARIABLE operands inside a transform (fused ring products)
     u64 bar_mu;
     int bar_sh1, bar_sh2;
@@ -352,6 +358,8 @@ struct ArithDS {
         const FHE_CONST uint4 *tw, *twi;
         uint4 ninv, ninv_w;
         int pb, prefix;
+        const FHE_CONST uint4 *tw3i;  // ModDesc::twd3i
+        unsigned tw3_stride;
     };
     static constexpr int PREFETCH = 4;
     static __host__ __device__ __forceinline__ uint4 split(u64 w, u64 q) {
@@ -375,6 +383,7 @@ struct ArithDS {
         k.ninv = pb ? D.ds_one : D.ds_ninv[log_n_total];
         k.ninv_w = D.ds_ninv_w[log_n_total];
         k.pb = pb; k.prefix = prefix;
+        k.tw3i = as_const(D.twd3i); k.tw3_stride = D.twd3_stride;
         return k;
     }
     // w y mod q, unreduced: < 2^(B+3) for any y

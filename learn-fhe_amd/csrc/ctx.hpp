@@ -24,6 +24,7 @@ struct fhe_ctx {
     fhe::TwPair *d_tw = nullptr, *d_twi = nullptr;  // {w, floor(w 2^64 / q)} pairs in HBM
     u64 *d_tww = nullptr, *d_twwi = nullptr;        // plain twiddles for the pseudo-Mersenne path (null if not eligible)
     uint4 *d_twd = nullptr, *d_twdi = nullptr;      // the same twiddles in the two-operand split form (ArithDS, arith.hpp)
+    uint4 *d_twd3i = nullptr;                       // ModDesc::twd3i: [7][cap / 4] powers of the last-layer inverse twiddles (arith.hpp)
     int pm_b = 0;                                   // q = 2^pm_b - pm_c, or 0
     unsigned pm_c = 0;
     fhe::ModDesc *d_desc = nullptr;                 // this modulus as the kernels read it (1 entry)

@@ -428,6 +428,72 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
     STAMP_FLUSH();
 }
 
+// ---- pass 3 of the inverse in diagonal form (two-operand policy) -------------------------------------------------------
+// The inverse meets its N/2 + N/4 + N/8 per-lane twiddles FIRST, together with the HBM loads, where nothing can hide their
+// latency (the forward meets them last and fetches a pass ahead).  Within one block of 8 contiguous coefficients the three
+// layers factor as  diag(1, t, .., t^7) . F8  with t = twi[4 blk] and F8 the same network with t = 1: its only twiddles are
+// I^-1 = twi[1], J^-1 = twi[2] and (I J)^-1 = twi[3] (psi^(-N/2), psi^(-N/4), psi^(-3N/4): wave uniform, scalar registers).
+// So the butterflies of a replica start as soon as its coefficients arrive, and the seven per-lane multipliers t^p -- a table
+// laid out [p][blk], consecutive lanes on consecutive entries -- are first needed 24 additions and 5 products later.
+// Same multiplications (12 per block), same additions as three butterfly layers; results equal mod q, so canonical outputs
+// are bit-identical.  Bounds (inputs canonical): every sum stays below 8.2 q < 2^64; products come back below q + 9c.
+template <class A>
+__device__ __host__ constexpr bool w14_p3_diag() {
+#ifdef W14_NO_DIAG
+    return false;
+#else
+    return std::is_same<typename A::TwRaw, uint4>::value;
+#endif
+}
+
+template <class A, int R0, int AB>
+__device__ __forceinline__ int p3_blk(int t3, const typename A::K &k) {
+    return (1 << (R0 + 8 + k.pb)) + ((k.prefix << (R0 + 8)) | t3 | (AB << 6));
+}
+template <class A, int R0, int AB>
+__device__ __forceinline__ void p3_diag_load(uint4 (&e)[7], int t3, const typename A::K &k) {
+    const int blk = p3_blk<A, R0, AB>(t3, k);
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        const FHE_CONST uint4 *q = k.tw3i + size_t(p) * k.tw3_stride + blk;
+        e[p] = uint4{q->x, q->y, q->z, q->w};
+    }
+}
+// F8 on x[8 AB .. 8 AB + 7] (position = register index), then the diagonal; NEXT >= 0: every multiplier slot is refilled for
+// replica NEXT as soon as it has been used
+template <class A, int R0, int AB, int NEXT>
+__device__ __forceinline__ void p3_diag_apply(u64 (&x)[32], uint4 (&e)[7], const uint4 &ci, const uint4 &cj, const uint4 &cij, int t3,
+                                              const typename A::K &k) {
+    const auto &m = k.m;
+    u64 *v = x + 8 * AB;
+    // layer A: pairs (2j, 2j + 1)
+    const u64 s0 = v[0] + v[1], t0 = v[0] + m.q2 - v[1];
+    const u64 s1 = v[2] + v[3], t1 = A::mul(v[2] + m.q2 - v[3], ci, m);
+    const u64 s2 = v[4] + v[5], t2 = A::mul(v[4] + m.q2 - v[5], cj, m);
+    const u64 s3 = v[6] + v[7], t3v = A::mul(v[6] + m.q2 - v[7], cij, m);
+    // layer B: pairs (4j + k, 4j + 2 + k)
+    const u64 u0 = s0 + s1, e0 = s0 + m.q4 - s1;              // s < 2q
+    const u64 u1 = t0 + t1, e1 = t0 + m.q2 - t1;              // t0 < 3q, t1 < q + 9c
+    const u64 u2 = s2 + s3, e2 = A::mul(s2 + m.q4 - s3, ci, m);
+    const u64 u3 = t2 + t3v, e3 = A::mul(t2 + m.q2 - t3v, ci, m);
+    // layer C: pairs (k, 4 + k); then the diagonal
+    const int blk = NEXT >= 0 ? p3_blk<A, R0, (NEXT >= 0 ? NEXT : 0)>(t3, k) : 0;
+    auto refill = [&](int p) {
+        if constexpr (NEXT >= 0) {
+            const FHE_CONST uint4 *q = k.tw3i + size_t(p) * k.tw3_stride + blk;
+            e[p] = uint4{q->x, q->y, q->z, q->w};
+        }
+    };
+    v[0] = A::fold1(u0 + u2, m);                              // < 8q: the one value no product reduces
+    v[1] = A::mul(u1 + u3, e[0], m); refill(0);
+    v[2] = A::mul(e0 + e2, e[1], m); refill(1);
+    v[3] = A::mul(e1 + e3, e[2], m); refill(2);
+    v[4] = A::mul(u0 + m.q4 - u2, e[3], m); refill(3);        // u2 < 4q
+    v[5] = A::mul(u1 + m.q4 - u3, e[4], m); refill(4);        // u3 < 2q + 18c
+    v[6] = A::mul(e0 + m.q2 - e2, e[5], m); refill(5);        // e2 < q + 9c
+    v[7] = A::mul(e1 + m.q2 - e3, e[6], m); refill(6);
+}
+
 // One inverse transform; x[] arrives loaded in the pass-3 layout, d[] with the pass-3 twiddles of replicas 0 and 1 (fetched BEFORE
 // the coefficients: vmcnt retires in order, and the twiddles are L2 hits).
 template <class A, bool PFX, int R0>
@@ -444,6 +510,18 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     // registers it leaves free.
     constexpr bool REFILL = w14_p3_refill<A>();
     Tw c3[8], c2[4], c1[2], c0[1];
+    if constexpr (w14_p3_diag<A>()) {
+        uint4(&e)[7] = reinterpret_cast<uint4(&)[7]>(d[0]);   // Tw7 of a 16-byte policy = seven uint4
+        const uint4 ci = A::template fetch<true>(k, 1), cj = A::template fetch<true>(k, 2), cij = A::template fetch<true>(k, 3);
+        FHE_SCHED_FENCE();
+        p3_diag_apply<A, R0, 0, 1>(x, e, ci, cj, cij, t3, k);
+        FHE_SCHED_FENCE();
+        p3_diag_apply<A, R0, 1, 2>(x, e, ci, cj, cij, t3, k);
+        FHE_SCHED_FENCE();
+        p3_diag_apply<A, R0, 2, 3>(x, e, ci, cj, cij, t3, k);
+        FHE_SCHED_FENCE();
+        p3_diag_apply<A, R0, 3, -1>(x, e, ci, cj, cij, t3, k);
+    } else
     static_for<0, 4>([&](auto abc) {
         constexpr int ab = decltype(abc)::value, nx = ab < 3 ? ab + 1 : 3;
         Tw7<A> &e = d[REFILL ? 0 : ab & 1];
@@ -460,10 +538,15 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     });
     FHE_SCHED_FENCE();
     STAMP(1);
-    tw_load<A, true, P2<R0, 3>>(c3, t2, k);
+    // pass 2's first twiddle set is requested BEHIND the exchange when it is 32 registers wide: held across the exchange it pushes
+    // the allocator over 128 registers, and a spilled twiddle comes back through scratch memory behind every load in flight
+    // (vmcnt retires in order): 0.307 -> 0.294 ms per 4096 transforms
+    constexpr bool C3_LATE = sizeof(Tw) > 8;
+    if constexpr (!C3_LATE) tw_load<A, true, P2<R0, 3>>(c3, t2, k);
     xchg_32(x, lane, wl);
     STAMP(2);
     FHE_SCHED_FENCE();
+    if constexpr (C3_LATE) tw_load<A, true, P2<R0, 3>>(c3, t2, k);
     tw_load<A, true, P2<R0, 2>>(c2, t2, k);
     gs_apply<A, P2<R0, 3>, 3>(x, c3, k);
     FHE_SCHED_FENCE();
@@ -574,8 +657,9 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     u64 *g = data + (size_t(sub) << LOG_N);
     u64 x[32];
     w14::Tw7<A> d[2];
-    w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
-    if constexpr (!w14::w14_p3_refill<A>()) w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
+    if constexpr (w14::w14_p3_diag<A>()) w14::p3_diag_load<A, R0, 0>(reinterpret_cast<uint4(&)[7]>(d[0]), (w << 8) | lane, k);
+    else w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
+    if constexpr (!w14::w14_p3_diag<A>() && !w14::w14_p3_refill<A>()) w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
     const int off = (w << 11) | (lane << 3);
     const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g) + off;
     if constexpr (MUL) {

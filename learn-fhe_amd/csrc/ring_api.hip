@@ -101,14 +101,14 @@ int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, 
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
     if (log_n == 15) {  // whole 2^15 rings in one pass over HBM (ntt14w.hpp, R0 = 4): one workgroup of 1024 threads per CU
-        if (pm == 60) return launch14<fhe::ArithDS<60>, fhe::ArithPM<60>, 4>(inv, d, nd, a, subs, 0, st, io);
-        if (pm == 54) return launch14<fhe::ArithDS<54>, fhe::ArithPM<54>, 4>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 60) return launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 4>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 54) return launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 4>(inv, d, nd, a, subs, 0, st, io);
         return launch14<fhe::ArithShoup, fhe::ArithShoup, 4>(inv, d, nd, a, subs, 0, st, io);
     }
     if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st, io);
-    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithPM<60>>(inv, d, nd, a, subs, pb, st, io)
+    if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithDS<60>>(inv, d, nd, a, subs, pb, st, io)
                                      : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st, io);
-    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithPM<54>>(inv, d, nd, a, subs, pb, st, io)
+    if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithDS<54>>(inv, d, nd, a, subs, pb, st, io)
                                      : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st, io);
     return log_n == 14 ? launch14<fhe::ArithShoup, fhe::ArithShoup>(inv, d, nd, a, subs, pb, st, io)
                        : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st, io);
@@ -286,6 +286,19 @@ int fhe_ctx_create(uint64_t q, int device, fhe_ctx **out) {
             c->d_twdi = c->d_twd + cap;
             if (e == hipSuccess) e = hipMemcpy(c->d_twd, df.data(), cap * sizeof(uint4), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(c->d_twdi, di.data(), cap * sizeof(uint4), hipMemcpyHostToDevice);
+            // diagonal multipliers of the inverse's first pass (ntt14w.hpp): twd3i[(p - 1) stride + blk] = twi[4 blk]^p, p = 1..7
+            if (e == hipSuccess && cap >= 8) {
+                const size_t stride = cap / 4;
+                std::vector<uint4> d3(7 * stride, uint4{0, 0, 0, 0});
+                for (size_t blk = 1; blk < stride; ++blk) {
+                    const uint64_t th = c->twi[4 * blk];
+                    uint64_t pw = th;
+                    for (int p = 0; p < 7; ++p) { d3[p * stride + blk] = split(pw); pw = fhe::mulmod(pw, th, q); }
+                }
+                e = hipMalloc((void **)&c->d_twd3i, d3.size() * sizeof(uint4));
+                if (e == hipSuccess) e = hipMemcpy(c->d_twd3i, d3.data(), d3.size() * sizeof(uint4), hipMemcpyHostToDevice);
+                c->h_desc.twd3i = c->d_twd3i; c->h_desc.twd3_stride = (unsigned)stride;
+            }
         }
         c->h_desc.tww = c->d_tww;
         c->h_desc.twwi = c->d_twwi;
@@ -324,6 +337,7 @@ void fhe_ctx_destroy(fhe_ctx *c) {
         if (c->d_desc) (void)hipFree(c->d_desc);
         if (c->d_tww) (void)hipFree(c->d_tww);
         if (c->d_twd) (void)hipFree(c->d_twd);
+        if (c->d_twd3i) (void)hipFree(c->d_twd3i);
     }
     delete c;
 }

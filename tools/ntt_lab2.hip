@@ -108,6 +108,19 @@ int main(int argc, char **argv) {
         hd.twd = dd; hd.twdi = ddi; hd.ds_pow = 1u << (60 - 31);
         for (int k = 0; k < 20; ++k) { hd.ds_ninv[k] = ArithDS<60>::split(hd.ninv[k], q); hd.ds_ninv_w[k] = ArithDS<60>::split(hd.ninv_w[k], q); }
         hd.ds_one = ArithDS<60>::split(1, q);
+        {   // diagonal multipliers of the inverse's first pass: twd3i[(p - 1) * stride + blk] = twi[4 blk]^p
+            const size_t stride = cap / 4;
+            std::vector<uint4> d3(7 * stride);
+            for (size_t blk = 1; blk < stride; ++blk) {
+                const u64 th = twi[4 * blk].w;
+                u64 pw2 = th;
+                for (int pp = 0; pp < 7; ++pp) { d3[pp * stride + blk] = ArithDS<60>::split(pw2, q); pw2 = mulmod(pw2, th, q); }
+            }
+            uint4 *dd3;
+            hipMalloc(&dd3, d3.size() * 16);
+            hipMemcpy(dd3, d3.data(), d3.size() * 16, hipMemcpyHostToDevice);
+            hd.twd3i = dd3; hd.twd3_stride = (unsigned)stride;
+        }
     }
     ModDesc *d_desc;
     hipMalloc(&d_desc, sizeof(ModDesc));
