@@ -84,9 +84,8 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 
 // N = 2^14 (and the 2^14 sub-transforms of larger rings): the register-resident, wave-local kernels of ntt14w.hpp, two
 // workgroups per CU.  AF / AI: the arithmetic policy of each direction (measured, tools/ntt_lab2.hip, 4096 transforms at 60 bits:
-// forward 0.274 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.317 against
-// 0.320 -- a tie: the inverse meets its twiddle-heavy passes first, with the coefficients still on their way from HBM, and there
-// the 16-byte form costs in L2 traffic and registers what it saves in instructions.  The inverse keeps the 8-byte tables.)
+// forward 0.274 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.296 against
+// 0.320 since its first pass runs in diagonal form and nothing spills: ntt14w.hpp).
 template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
