@@ -163,6 +163,19 @@ int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size
     return FHE_OK;
 }
 
+// N = 2^15 with the outermost layer left to the caller (rns_kernels.hpp, the edge kernels of the key switch): what remains of
+// every polynomial are two independent 2^14 sub-transforms -- the two-workgroups-per-CU kernel instead of the one-per-CU 2^15 one.
+// Forward: the caller has applied layer 0; inverse: the caller applies layer 0 and n^-1.  io counts polynomials.
+int ntt_fwd_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch, hipStream_t st, int pm, NttIo io) {
+    if (io.mul) return FHE_ERR_INVALID;
+    io.src_mod <<= 1;
+    return sub_fwd(descs, n_desc, a, 14, batch << 1, 1, pm, st, io);
+}
+int ntt_inv_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch, hipStream_t st, int pm, NttIo io) {
+    io.src_mod <<= 1; io.mul_div <<= 1; io.mul_period <<= 1;
+    return sub_inv(descs, n_desc, a, 14, batch << 1, 1, pm, st, io);
+}
+
 int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_fwd_multi(c->d_desc, 1, a, log_n, batch, st, c->pm_b); }
 int ntt_inv_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_inv_multi(c->d_desc, 1, a, log_n, batch, st, c->pm_b); }
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <set>
@@ -25,6 +26,7 @@ struct fhe_rns_ctx {
     bool ds = false;                   // every modulus is a 60-bit pseudo-Mersenne prime: conversions on the two-operand products    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
     int max_log_n = 0;                 // largest ring degree every prime supports
     int all_pm = -1;                   // common pseudo-Mersenne bit length of all primes, 0 if none
+    fhe::EdgeConsts edge{};            // the transforms' outermost layer at N = 2^15 (rns_kernels.hpp), present when `ds`
 };
 
 struct fhe_ckks_key {
@@ -181,6 +183,13 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     for (int i = 0; i < L; ++i) put_ds(pinv_ds, pinv[i], qs[i]);
     if (bb.words.size() & 1) bb.words.push_back(0);
     const size_t o_pids = bb.put(pinv_ds);
+    // tw[1], n^-1 and n^-1 twi[1] of every modulus at n = 2^15 (the edge kernels; read only when `ds`)
+    std::vector<uint64_t> e_w, e_n, e_nw;
+    for (int i = 0; i < L + K; ++i) {
+        const fhe_ctx *c = r->mods[i];
+        put_ds(e_w, c->tw.size() > 1 ? c->tw[1] : 0, c->q); put_ds(e_n, c->ninv[15], c->q); put_ds(e_nw, c->ninv_w[15], c->q);
+    }
+    const size_t o_ew = bb.put(e_w), o_en = bb.put(e_n), o_enw = bb.put(e_nw);
     // rns.rs:99-101 `rescale()`: the same formulas with P = the last q-limb (rns.rs:104-111, the K == 1 branch)
     std::vector<uint64_t> lhalf_q(L), lhalf_p(1), lpinv(L), lpinv_s(L);
     if (L >= 2) {
@@ -218,6 +227,7 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     r->resc.pinv_ds = (const uint4 *)(base + o_pids);
     r->resc.p2q = r->p2q;
     r->ds = r->all_pm == 60;
+    r->edge = fhe::EdgeConsts{(const uint4 *)(base + o_ew), (const uint4 *)(base + o_en), (const uint4 *)(base + o_enw)};
     r->resc_last = r->resc;  // p2q unused when K == 1
     r->resc_last.L = L - 1; r->resc_last.K = 1;
     r->resc_last.p_mod = r->q2p.a_mod + (L - 1);
@@ -259,6 +269,24 @@ void launch_rescale(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const 
                         else hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R); } while (0)
     RNS_BOUND(R.K, CALL);
 #undef CALL
+}
+// the same two kernels with the outermost transform layer of a 2^15 ring in them (rns_kernels.hpp); two-operand products only
+void launch_extend_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, const fhe::EdgeConsts &E,
+                        hipStream_t st) {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_edge_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, E.fwd_w)
+    RNS_BOUND(C.la, CALL);
+#undef CALL
+}
+void launch_rescale_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
+                         const fhe::RescaleConsts &R, const fhe::EdgeConsts &E, hipStream_t st) {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R, E)
+    RNS_BOUND(R.K, CALL);
+#undef CALL
+}
+// FHE_RING_NO_EDGE=1: the key switch keeps whole 2^15 transforms (A/B runs and the test that both routes agree bit for bit)
+bool edge_enabled() {
+    const char *e = getenv("FHE_RING_NO_EDGE");
+    return !(e && e[0] == '1');
 }
 }  // namespace
 
@@ -389,6 +417,25 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
     u64 *ws = wsp.as<u64>();
     u64 *ext = ws, *pb = ws + blk;
     int rc = FHE_OK;
+    if (log_n == 15 && r->ds && r->L <= fhe::RNS_MAX_LIMBS && edge_enabled()) {
+        // N = 2^15 (cfg4): layer 0 of the forward transforms runs inside the extend kernel, layer 0 of the inverse ones (and n^-1)
+        // inside the rescales; the transform launches are 2^14 sub-transforms, two workgroups per CU (rns_kernels.hpp)
+        launch_extend_edge(a_in, L * n, ext, lk * n, n, batch, r->q2p, r->edge, st);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        if (rc == FHE_OK) rc = fhe::ntt_fwd_inner15(r->d_descs, (unsigned)lk, ext, batch * lk, st, r->all_pm);
+        if (rc == FHE_OK) {
+            fhe::NttIo io;
+            io.src = ext; io.src_mod = (unsigned)(batch * lk);
+            io.mul = key->d_kb; io.mul_div = (unsigned)(batch * lk); io.mul_period = (unsigned)lk;
+            rc = fhe::ntt_inv_inner15(r->d_descs, (unsigned)lk, pb, 2 * batch * lk, st, r->all_pm, io);
+        }
+        if (rc == FHE_OK) {
+            launch_rescale_edge(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, r->edge, st);
+            launch_rescale_edge(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, r->edge, st);
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+        return rc;
+    }
     // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps): one kernel, the q-limbs written back out of the registers it read them into
     launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, r->ds, st, ext, lk * n);
     if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;

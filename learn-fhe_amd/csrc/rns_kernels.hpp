@@ -125,6 +125,23 @@ struct RescaleConsts {
     BaseConv p2q;                      // switch_bases P -> Q                (rns.rs:93-97)
 };
 
+// One q-limb of `rescale_k` (rns.rs:103-118): x = the limb's value, vp / vs / u = the rounded p-limbs and their conversion state
+template <int MAXA, bool FULL, bool DS>
+__device__ __forceinline__ u64 rescale_limb(const RescaleConsts &R, int l, u64 q, u64 x, const u64 (&vp)[MAXA], const u64 (&vs)[MAXA], int u) {
+    const u64 vq = csub(x + ldc(R.half_q, l), q);
+    u64 sw;
+    if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
+        const u64 y = vp[0];
+        sw = y - __umul64hi(y, ldc(R.red_mu, l)) * q;
+        sw = csub(csub(sw, q), q);
+    } else {
+        sw = base_conv_out<MAXA, FULL, DS>(R.p2q, l, vs, u);
+    }
+    const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
+    if constexpr (DS) return csub(ArithDS<60>::mul(diff, ldc4(R.pinv_ds, l), rns_dsk(q, ldc(R.p2q.b_c, l))), q);
+    else return csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
+}
+
 // util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot)
 template <int MAXA, bool FULL, bool DS = false>
@@ -144,21 +161,115 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
             const int l = l0 + ll;
             if (l >= R.L) continue;
             const u64 q = ldc(R.q_mod, l);
-            const u64 vq = csub(in[p * in_bs + size_t(l) * n + i] + ldc(R.half_q, l), q);
-            u64 sw;
-            if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
-                const u64 x = vp[0];
-                sw = x - __umul64hi(x, ldc(R.red_mu, l)) * q;
-                sw = csub(csub(sw, q), q);
-            } else {
-                sw = base_conv_out<MAXA, FULL, DS>(R.p2q, l, vs, u);
-            }
-            const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
-            u64 r;
-            if constexpr (DS) r = csub(ArithDS<60>::mul(diff, ldc4(R.pinv_ds, l), rns_dsk(q, ldc(R.p2q.b_c, l))), q);
-            else r = csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
+            u64 r = rescale_limb<MAXA, FULL, DS>(R, l, q, in[p * in_bs + size_t(l) * n + i], vp, vs, u);
             if (addend) r = csub(r + addend[p * add_bs + size_t(l) * n + i], q);
             out[p * out_bs + size_t(l) * n + i] = r;
+          }
+        }
+    }
+}
+
+// ---- the key switch at N = 2^15: the transforms' OUTERMOST layer runs in their neighbours -------------------------------------
+// A 2^15 ring does not fit the two-workgroups-per-CU kernel of ntt14w.hpp; as ONE workgroup per CU (R0 = 4) its memory phases
+// and its butterflies do not overlap across workgroups and it runs at two thirds of the 2^14 kernel's rate.  But layer 0 of
+// the forward transform (util/src/ring/fft.rs:42-52 with m = 1: the pairs (i, i + n/2), ONE twiddle tw[1]) and layer 0 of the
+// inverse (fft.rs:62-76, twi[1], then n^-1) are elementwise over such pairs -- exactly the shape of the per-coefficient kernels
+// that produce the forward's input (`extend_bases`) and consume the inverse's output (`rescale_k`).  With a thread of those
+// kernels owning the pair (i, i + n/2) the layer costs them the products the transform would have spent on it, and what is left
+// of every transform is two INDEPENDENT 2^14 sub-transforms (ntt14w PFX form, pb = 1).  All arithmetic is exact mod q_l, so the
+// coefficient-domain results are bit-identical.  Two-operand products only (every modulus a 60-bit pseudo-Mersenne prime).
+struct EdgeConsts {
+    const uint4 *fwd_w;   // [L + K] tw[1] of every modulus (qs then ps)
+    const uint4 *inv_n;   // [L + K] n^-1
+    const uint4 *inv_nw;  // [L + K] n^-1 twi[1]
+};
+// (X, Y) <- (X + w Y, X - w Y), canonical in and out (fft.rs:96-101 `dit`)
+__device__ __forceinline__ void edge_ct(u64 &X, u64 &Y, const uint4 &w, const DsK &m) {
+    const u64 t = csub(ArithDS<60>::mul(Y, w, m), m.q), x = X;
+    X = csub(x + t, m.q);
+    Y = x >= t ? x - t : x + m.q - t;
+}
+// (X, Y) <- ((X + Y) n^-1, (X - Y) twi[1] n^-1), canonical in and out (fft.rs:108-113 `dif`, then fft.rs:73-76)
+__device__ __forceinline__ void edge_gs(u64 &X, u64 &Y, const uint4 &nv, const uint4 &nw, const DsK &m) {
+    const u64 s = X + Y, d = X + m.q - Y;
+    X = csub(ArithDS<60>::mul(s, nv, m), m.q);
+    Y = csub(ArithDS<60>::mul(d, nw, m), m.q);
+}
+
+// extend_bases + layer 0 of the forward transform of all la + lb limbs: in [batch][la][n] -> out [batch][la + lb][n]
+template <int MAXA, bool FULL>
+__global__ void rns_extend_edge_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
+                                       BaseConv C, const uint4 *__restrict__ fwd_w) {
+    const size_t h = n >> 1, total = h * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / h, i = idx - p * h;
+        const u64 *src = in + p * in_bs + i;
+        u64 *dst = out + p * out_bs + i;
+        u64 v0[MAXA], v1[MAXA], vs0[MAXA], vs1[MAXA];
+#pragma unroll
+        for (int l = 0; l < MAXA; ++l) {
+            v0[l] = (FULL || l < C.la) ? src[size_t(l) * n] : 0;
+            v1[l] = (FULL || l < C.la) ? src[size_t(l) * n + h] : 0;
+        }
+        const int u0 = base_conv_prepare<MAXA, FULL, true>(C, v0, vs0);
+        const int u1 = base_conv_prepare<MAXA, FULL, true>(C, v1, vs1);
+#pragma unroll
+        for (int l = 0; l < MAXA; ++l)
+            if (FULL || l < C.la) {
+                edge_ct(v0[l], v1[l], ldc4(fwd_w, l), rns_dsk(ldc(C.a_mod, l), ldc(C.a_c, l)));
+                dst[size_t(l) * n] = v0[l];
+                dst[size_t(l) * n + h] = v1[l];
+            }
+        const int la = FULL ? MAXA : C.la;
+        for (int j0 = 0; j0 < C.lb; j0 += MAXA) {
+#pragma unroll
+            for (int jj = 0; jj < MAXA; ++jj) {
+                const int j = j0 + jj;
+                if (j >= C.lb) continue;
+                u64 o0 = base_conv_out<MAXA, FULL, true>(C, j, vs0, u0), o1 = base_conv_out<MAXA, FULL, true>(C, j, vs1, u1);
+                edge_ct(o0, o1, ldc4(fwd_w, la + j), rns_dsk(ldc(C.b_mod, j), ldc(C.b_c, j)));
+                dst[size_t(la + j) * n] = o0;
+                dst[size_t(la + j) * n + h] = o1;
+            }
+        }
+    }
+}
+
+// layer 0 of the inverse transform (+ n^-1) of all L + K limbs + rescale_k: in [batch][L+K][n] -> out [batch][L][n] (+ addend)
+template <int MAXA, bool FULL>
+__global__ void rns_rescale_edge_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
+                                        size_t n, size_t batch, RescaleConsts R, EdgeConsts E) {
+    const size_t h = n >> 1, total = h * batch;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / h, i = idx - p * h;
+        const u64 *src = in + p * in_bs + i;
+        u64 vp0[MAXA], vp1[MAXA], vs0[MAXA], vs1[MAXA];
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) {
+            if (FULL || j < R.K) {
+                const u64 pm = ldc(R.p_mod, j), hp = ldc(R.half_p, j);
+                u64 x = src[size_t(R.L + j) * n], y = src[size_t(R.L + j) * n + h];
+                edge_gs(x, y, ldc4(E.inv_n, R.L + j), ldc4(E.inv_nw, R.L + j), rns_dsk(pm, ldc(R.p2q.a_c, j)));
+                vp0[j] = csub(x + hp, pm); vp1[j] = csub(y + hp, pm);
+            } else {
+                vp0[j] = 0; vp1[j] = 0;
+            }
+        }
+        int u0 = 0, u1 = 0;
+        if (R.K > 1) { u0 = base_conv_prepare<MAXA, FULL, true>(R.p2q, vp0, vs0); u1 = base_conv_prepare<MAXA, FULL, true>(R.p2q, vp1, vs1); }
+        for (int l0 = 0; l0 < R.L; l0 += MAXA) {
+#pragma unroll
+          for (int ll = 0; ll < MAXA; ++ll) {
+            const int l = l0 + ll;
+            if (l >= R.L) continue;
+            const u64 q = ldc(R.q_mod, l);
+            u64 x = src[size_t(l) * n], y = src[size_t(l) * n + h];
+            edge_gs(x, y, ldc4(E.inv_n, l), ldc4(E.inv_nw, l), rns_dsk(q, ldc(R.p2q.b_c, l)));
+            u64 r0 = rescale_limb<MAXA, FULL, true>(R, l, q, x, vp0, vs0, u0), r1 = rescale_limb<MAXA, FULL, true>(R, l, q, y, vp1, vs1, u1);
+            const size_t ao = p * add_bs + size_t(l) * n + i, oo = p * out_bs + size_t(l) * n + i;
+            if (addend) { r0 = csub(r0 + addend[ao], q); r1 = csub(r1 + addend[ao + h], q); }
+            out[oo] = r0;
+            out[oo + h] = r1;
           }
         }
     }

@@ -126,6 +126,29 @@ def test_ckks_key_switch_cfg4(fhe, cref, torch_cuda):
     assert np.array_equal(host(b)[0], eb) and np.array_equal(host(a)[0], ea)
 
 
+@pytest.mark.parametrize("big_l,big_k", [(3, 3), (2, 1), (5, 2), (9, 3)])
+def test_ckks_key_switch_2p15_edge_route(fhe, cref, torch_cuda, big_l, big_k, monkeypatch):
+    """N = 2^15 on 60-bit pseudo-Mersenne primes: the key switch runs layer 0 of its transforms inside the extend / rescale kernels
+    (rns_kernels.hpp, edge kernels) and 2^14 sub-transforms in between.  Ragged limb counts (predicated instantiations, the K = 1
+    shortcut of rescale_k, L above the register bound): bit-equal to the oracle AND to the route with whole 2^15 transforms."""
+    n, batch = 1 << 15, 2
+    primes = cref.two_adic_primes(60, 16, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(41, qs + ps, n), rand_limbs(42, qs + ps, n)
+    cb, ca = rand_limbs(43, qs, n, batch), rand_limbs(44, qs, n, batch)
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    b, a = dev(torch_cuda, cb), dev(torch_cuda, ca)
+    key.key_switch_(b, a)
+    monkeypatch.setenv("FHE_RING_NO_EDGE", "1")
+    b2, a2 = dev(torch_cuda, cb), dev(torch_cuda, ca)
+    key.key_switch_(b2, a2)
+    monkeypatch.delenv("FHE_RING_NO_EDGE")
+    assert np.array_equal(host(b), host(b2)) and np.array_equal(host(a), host(a2))
+    eb, ea = cref.ckks_key_switch(qs, ps, kb, ka, cb[0], ca[0])
+    assert np.array_equal(host(b)[0], eb) and np.array_equal(host(a)[0], ea)
+
+
 def test_rns_errors(fhe):
     import ctypes as C
     lib = fhe.lib()
