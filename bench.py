@@ -177,7 +177,7 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
     del c4
     # ct in 2L 8N + ksk 2(L+K) 8N + ct out 2L 8N = 16 MiB at cfg4
     out["roofline"] = roof(out["key_switches_per_sec_batch%d" % (8 * batch)], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
-                           "rns_extend + ntt14w_fwd<R0=4> + ntt14w_inv<R0=4> (2^15 rings in one pass; ksk products fused into the inverse's load) + rns_rescale x2",
+                           "rns_extend_edge (base extension + layer 0 of the forward transforms) + ntt14w_fwd<PFX> + ntt14w_inv<PFX, MUL> (2^14 sub-transforms, two workgroups per CU; ksk products fused into the inverse's load) + rns_rescale_edge x2 (layer 0 of the inverse transforms, n^-1, rescale_k)",
                            "the base conversions mix limbs, so extend / transforms / rescales stay separate passes over the limbs: ~4x the algorithmic bytes move")
     return out
 

@@ -115,6 +115,7 @@ fhe::BaseConv conv_view(const ConvOffsets &o, const uint64_t *base) {
     C.b_mod = (const u64 *)base + o.b_mod; C.c = (const u64 *)base + o.c; C.c_s = (const u64 *)base + o.c_s; C.ua = (const u64 *)base + o.ua;
     C.ahat_inv_ds = (const uint4 *)(base + o.inv_ds); C.c_ds = (const uint4 *)(base + o.c_ds);
     C.a_c = (const unsigned *)(base + o.a_c); C.b_c = (const unsigned *)(base + o.b_c);
+    C.pw = 1u << 29;
     return C;
 }
 
@@ -279,7 +280,7 @@ void launch_extend_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, si
 }
 void launch_rescale_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
                          const fhe::RescaleConsts &R, const fhe::EdgeConsts &E, hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R, E)
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R, E)
     RNS_BOUND(R.K, CALL);
 #undef CALL
 }
@@ -417,7 +418,7 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
     u64 *ws = wsp.as<u64>();
     u64 *ext = ws, *pb = ws + blk;
     int rc = FHE_OK;
-    if (log_n == 15 && r->ds && r->L <= fhe::RNS_MAX_LIMBS && edge_enabled()) {
+    if (log_n == 15 && r->ds && r->L <= 8 && r->K <= 8 && edge_enabled()) {  // (wider bases: two limb vectors per thread would spill)
         // N = 2^15 (cfg4): layer 0 of the forward transforms runs inside the extend kernel, layer 0 of the inverse ones (and n^-1)
         // inside the rescales; the transform launches are 2^14 sub-transforms, two workgroups per CU (rns_kernels.hpp)
         launch_extend_edge(a_in, L * n, ext, lk * n, n, batch, r->q2p, r->edge, st);

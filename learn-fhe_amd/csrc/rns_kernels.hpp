@@ -35,9 +35,11 @@ struct BaseConv {
     const uint4 *ahat_inv_ds;  // [la]
     const uint4 *c_ds;         // [lb][la]
     const unsigned *a_c, *b_c; // [la], [lb]  2^60 - modulus
+    unsigned pw;               // 2^29, handed over as a VALUE the compiler cannot see: as a literal it turns the third product of
+                               // ArithDS::mul_raw into a 64-bit shift + a 64-bit add (two instructions for one multiply-add)
 };
 
-__device__ __forceinline__ DsK rns_dsk(u64 q, unsigned c) { return DsK{q, 2 * q, 4 * q, c, 2 * c, 1u << 29}; }
+__device__ __forceinline__ DsK rns_dsk(u64 q, unsigned c, unsigned pw) { return DsK{q, 2 * q, 4 * q, c, 2 * c, pw}; }
 __device__ __forceinline__ uint4 ldc4(const uint4 *p, int i) {
     const __attribute__((address_space(4))) uint4 *q = (const __attribute__((address_space(4))) uint4 *)p + i;
     return uint4{q->x, q->y, q->z, q->w};
@@ -55,7 +57,7 @@ __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&
     for (int i = 0; i < MAXA; ++i) {
         if (FULL || i < C.la) {
             const u64 a = ldc(C.a_mod, i);
-            if constexpr (DS) vs[i] = csub(ArithDS<60>::mul(v[i], ldc4(C.ahat_inv_ds, i), rns_dsk(a, ldc(C.a_c, i))), a);  // < q + 9c -> canonical
+            if constexpr (DS) vs[i] = csub(ArithDS<60>::mul(v[i], ldc4(C.ahat_inv_ds, i), rns_dsk(a, ldc(C.a_c, i), C.pw)), a);  // < q + 9c -> canonical
             else vs[i] = csub(mul_shoup_lazy(v[i], ldc(C.ahat_inv, i), ldc(C.ahat_inv_s, i), a), a);
             acc = __dadd_rn(acc, __dmul_rn(ldc(C.frac, i), (double)vs[i]));  // no FMA contraction: matches `.sum::<f64>()`
         } else {
@@ -65,26 +67,35 @@ __device__ __forceinline__ int base_conv_prepare(const BaseConv &C, const u64 (&
     return (int)round(acc);  // f64::round: half away from zero
 }
 
-// sum_i c_ji * vs_i - ua_j[u]  (mod b_j), canonical
-template <int MAXA, bool FULL, bool DS = false>
-__device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 (&vs)[MAXA], int u) {
+// sum_i c_ji * vs_i (mod b_j), canonical
+// LAZY (two-operand form only): the last conditional subtraction is left out, the result is < b_j + 9c
+template <int MAXA, bool FULL, bool DS = false, bool LAZY = false>
+__device__ __forceinline__ u64 base_conv_dot(const BaseConv &C, int j, const u64 (&vs)[MAXA]) {
     const int la = FULL ? MAXA : C.la;  // FULL: the source base has exactly MAXA limbs -- no predicate, constant strides
     const u64 b = ldc(C.b_mod, j), b2 = 2 * b;
     u64 dot = 0;
     if constexpr (DS) {
-        const DsK m = rns_dsk(b, ldc(C.b_c, j));
+        const DsK m = rns_dsk(b, ldc(C.b_c, j), C.pw);
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
             if (FULL || i < C.la) dot += ArithDS<60>::mul(vs[i], ldc4(C.c_ds, j * la + i), m);  // each < q + 9c: eight of them fit 2^63
             if ((i & 7) == 7 && i + 1 < MAXA) dot = ArithDS<60>::fold1(dot, m);
         }
-        dot = csub(ArithDS<60>::fold1(dot, m), b);  // < 2^60 + 9c < 2q
+        dot = ArithDS<60>::fold1(dot, m);  // < 2^60 + 8c = b + 9c
+        if constexpr (!LAZY) dot = csub(dot, b);
     } else {
 #pragma unroll
         for (int i = 0; i < MAXA; ++i)
             if (FULL || i < C.la) dot = csub(dot + mul_shoup_lazy(vs[i], ldc(C.c, j * la + i), ldc(C.c_s, j * la + i), b), b2);
         dot = csub(dot, b);
     }
+    return dot;
+}
+// ... - ua_j[u]  (mod b_j), canonical
+template <int MAXA, bool FULL, bool DS = false>
+__device__ __forceinline__ u64 base_conv_out(const BaseConv &C, int j, const u64 (&vs)[MAXA], int u) {
+    const int la = FULL ? MAXA : C.la;
+    const u64 dot = base_conv_dot<MAXA, FULL, DS>(C, j, vs), b = ldc(C.b_mod, j);
     const u64 sub = C.ua[j * (la + 1) + u];  // (u differs per lane: a vector load)
     return dot >= sub ? dot - sub : dot + b - sub;
 }
@@ -138,7 +149,7 @@ __device__ __forceinline__ u64 rescale_limb(const RescaleConsts &R, int l, u64 q
         sw = base_conv_out<MAXA, FULL, DS>(R.p2q, l, vs, u);
     }
     const u64 diff = vq >= sw ? vq - sw : vq + q - sw;
-    if constexpr (DS) return csub(ArithDS<60>::mul(diff, ldc4(R.pinv_ds, l), rns_dsk(q, ldc(R.p2q.b_c, l))), q);
+    if constexpr (DS) return csub(ArithDS<60>::mul(diff, ldc4(R.pinv_ds, l), rns_dsk(q, ldc(R.p2q.b_c, l), R.p2q.pw)), q);
     else return csub(mul_shoup_lazy(diff, ldc(R.pinv, l), ldc(R.pinv_s, l), q), q);
 }
 
@@ -196,11 +207,20 @@ __device__ __forceinline__ void edge_gs(u64 &X, u64 &Y, const uint4 &nv, const u
     Y = csub(ArithDS<60>::mul(d, nw, m), m.q);
 }
 
+// How the two kernels below are laid out (measured on the first, fully unrolled version: 230 scalar registers spilled into vector
+// lanes and read back -- 480 of 3470 vector instructions -- and, in the rescale, every limb's loads issued right before their use
+// behind the previous limb's stores, vmcnt retiring in order: 55 % of the wave cycles parked):
+//   * the loop over the OUTPUT limbs is rolled (`#pragma unroll 1`): one row of conversion constants (32 scalar registers) is live
+//     at a time, fetched by scalar loads at a run-time row index; the limb vectors stay in registers (indexed by unrolled loops);
+//   * everything a limb needs from memory (its coefficients, its addend, its (u A) mod b table entry) is requested ONE LIMB AHEAD,
+//     before the current limb's products start and before its results are stored, so no wait ever stands behind a store.
+
 // extend_bases + layer 0 of the forward transform of all la + lb limbs: in [batch][la][n] -> out [batch][la + lb][n]
 template <int MAXA, bool FULL>
 __global__ void rns_extend_edge_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
                                        BaseConv C, const uint4 *__restrict__ fwd_w) {
     const size_t h = n >> 1, total = h * batch;
+    const int la = FULL ? MAXA : C.la;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / h, i = idx - p * h;
         const u64 *src = in + p * in_bs + i;
@@ -213,64 +233,92 @@ __global__ void rns_extend_edge_kernel(const u64 *__restrict__ in, size_t in_bs,
         }
         const int u0 = base_conv_prepare<MAXA, FULL, true>(C, v0, vs0);
         const int u1 = base_conv_prepare<MAXA, FULL, true>(C, v1, vs1);
+        const u64 *ua0 = C.ua + u0, *ua1 = C.ua + u1;
+        u64 nsub0 = ua0[0], nsub1 = ua1[0];  // output limb 0's table entries fly under the source limbs' butterflies
 #pragma unroll
         for (int l = 0; l < MAXA; ++l)
             if (FULL || l < C.la) {
-                edge_ct(v0[l], v1[l], ldc4(fwd_w, l), rns_dsk(ldc(C.a_mod, l), ldc(C.a_c, l)));
+                edge_ct(v0[l], v1[l], ldc4(fwd_w, l), rns_dsk(ldc(C.a_mod, l), ldc(C.a_c, l), C.pw));
                 dst[size_t(l) * n] = v0[l];
                 dst[size_t(l) * n + h] = v1[l];
             }
-        const int la = FULL ? MAXA : C.la;
-        for (int j0 = 0; j0 < C.lb; j0 += MAXA) {
-#pragma unroll
-            for (int jj = 0; jj < MAXA; ++jj) {
-                const int j = j0 + jj;
-                if (j >= C.lb) continue;
-                u64 o0 = base_conv_out<MAXA, FULL, true>(C, j, vs0, u0), o1 = base_conv_out<MAXA, FULL, true>(C, j, vs1, u1);
-                edge_ct(o0, o1, ldc4(fwd_w, la + j), rns_dsk(ldc(C.b_mod, j), ldc(C.b_c, j)));
-                dst[size_t(la + j) * n] = o0;
-                dst[size_t(la + j) * n + h] = o1;
-            }
+#pragma unroll 1
+        for (int j = 0; j < C.lb; ++j) {
+            const u64 sub0 = nsub0, sub1 = nsub1;
+            if (j + 1 < C.lb) { nsub0 = ua0[(j + 1) * (la + 1)]; nsub1 = ua1[(j + 1) * (la + 1)]; }
+            const u64 b = ldc(C.b_mod, j);
+            const u64 d0 = base_conv_dot<MAXA, FULL, true>(C, j, vs0), d1 = base_conv_dot<MAXA, FULL, true>(C, j, vs1);
+            u64 o0 = d0 >= sub0 ? d0 - sub0 : d0 + b - sub0, o1 = d1 >= sub1 ? d1 - sub1 : d1 + b - sub1;
+            edge_ct(o0, o1, ldc4(fwd_w, la + j), rns_dsk(b, ldc(C.b_c, j), C.pw));
+            dst[size_t(la + j) * n] = o0;
+            dst[size_t(la + j) * n + h] = o1;
         }
     }
 }
 
-// layer 0 of the inverse transform (+ n^-1) of all L + K limbs + rescale_k: in [batch][L+K][n] -> out [batch][L][n] (+ addend)
+// layer 0 of the inverse transform (+ n^-1) of all L + K limbs + rescale_k: in [batch][L+K][n] -> out [batch][L][n] (+ addend).
+// ONE coefficient per lane: lanes 0..31 of a wave own coefficients i0 .. i0 + 31, lanes 32..63 own i0 + n/2 .. -- a lane's partner in
+// the layer-0 butterfly is lane ^ 32, reached with ds_bpermute (the LDS crossbar: no vector-ALU instruction, no LDS memory).  Two limb
+// vectors per lane (the pair-per-thread form of the extend kernel) need 128 registers here and spill.
+// canonical in; out < q + 9c (LAZY) or canonical
+template <bool LAZY>
+__device__ __forceinline__ void lane_gs(u64 &z, bool hi, const uint4 &nv, const uint4 &nw, const DsK &m) {
+    const u64 pz = __shfl_xor(z, 32);
+    const u64 t = pz + (hi ? m.q - z : z);  // low lane: x + y; high lane: x + q - y
+    const uint4 c{hi ? nw.x : nv.x, hi ? nw.y : nv.y, hi ? nw.z : nv.z, hi ? nw.w : nv.w};
+    z = ArithDS<60>::mul(t, c, m);
+    if constexpr (!LAZY) z = csub(z, m.q);
+}
 template <int MAXA, bool FULL>
 __global__ void rns_rescale_edge_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
                                         size_t n, size_t batch, RescaleConsts R, EdgeConsts E) {
-    const size_t h = n >> 1, total = h * batch;
-    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
-        const size_t p = idx / h, i = idx - p * h;
+    const size_t h = n >> 1, wpp = h >> 5, total_w = wpp * batch;  // wpp: waves per polynomial (n >= 64)
+    const int lane = threadIdx.x & 63, la = FULL ? MAXA : R.p2q.la;
+    const bool hi = lane >> 5;
+    for (size_t W = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) >> 6; W < total_w; W += (size_t(gridDim.x) * blockDim.x) >> 6) {
+        const size_t p = W / wpp, i = ((W - p * wpp) << 5) + (lane & 31) + (hi ? h : 0);
         const u64 *src = in + p * in_bs + i;
-        u64 vp0[MAXA], vp1[MAXA], vs0[MAXA], vs1[MAXA];
+        const u64 *ad = addend ? addend + p * add_bs + i : nullptr;
+        u64 *dst = out + p * out_bs + i;
+        u64 vp[MAXA], vs[MAXA];
 #pragma unroll
-        for (int j = 0; j < MAXA; ++j) {
+        for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < R.K) ? src[size_t(R.L + j) * n] : 0;
+        u64 nx = src[0], na = ad ? ad[0] : 0;  // q-limb 0 flies under the p-limbs' work
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j)
             if (FULL || j < R.K) {
-                const u64 pm = ldc(R.p_mod, j), hp = ldc(R.half_p, j);
-                u64 x = src[size_t(R.L + j) * n], y = src[size_t(R.L + j) * n + h];
-                edge_gs(x, y, ldc4(E.inv_n, R.L + j), ldc4(E.inv_nw, R.L + j), rns_dsk(pm, ldc(R.p2q.a_c, j)));
-                vp0[j] = csub(x + hp, pm); vp1[j] = csub(y + hp, pm);
-            } else {
-                vp0[j] = 0; vp1[j] = 0;
+                const u64 pm = ldc(R.p_mod, j);
+                lane_gs<false>(vp[j], hi, ldc4(E.inv_n, R.L + j), ldc4(E.inv_nw, R.L + j), rns_dsk(pm, ldc(R.p2q.a_c, j), R.p2q.pw));
+                vp[j] = csub(vp[j] + ldc(R.half_p, j), pm);
             }
-        }
-        int u0 = 0, u1 = 0;
-        if (R.K > 1) { u0 = base_conv_prepare<MAXA, FULL, true>(R.p2q, vp0, vs0); u1 = base_conv_prepare<MAXA, FULL, true>(R.p2q, vp1, vs1); }
-        for (int l0 = 0; l0 < R.L; l0 += MAXA) {
-#pragma unroll
-          for (int ll = 0; ll < MAXA; ++ll) {
-            const int l = l0 + ll;
-            if (l >= R.L) continue;
+        int u = 0;
+        if (R.K > 1) u = base_conv_prepare<MAXA, FULL, true>(R.p2q, vp, vs);
+        const u64 *ua = R.p2q.ua + u;
+        u64 nsub = R.K > 1 ? ua[0] : 0;
+#pragma unroll 1
+        for (int l = 0; l < R.L; ++l) {  // rolled, one limb ahead: see above
+            u64 x = nx;
+            const u64 a = na, sub = nsub;
+            if (l + 1 < R.L) {
+                nx = src[size_t(l + 1) * n];
+                if (ad) na = ad[size_t(l + 1) * n];
+                if (R.K > 1) nsub = ua[(l + 1) * (la + 1)];
+            }
             const u64 q = ldc(R.q_mod, l);
-            u64 x = src[size_t(l) * n], y = src[size_t(l) * n + h];
-            edge_gs(x, y, ldc4(E.inv_n, l), ldc4(E.inv_nw, l), rns_dsk(q, ldc(R.p2q.b_c, l)));
-            u64 r0 = rescale_limb<MAXA, FULL, true>(R, l, q, x, vp0, vs0, u0), r1 = rescale_limb<MAXA, FULL, true>(R, l, q, y, vp1, vs1, u1);
-            const size_t ao = p * add_bs + size_t(l) * n + i, oo = p * out_bs + size_t(l) * n + i;
-            if (addend) { r0 = csub(r0 + addend[ao], q); r1 = csub(r1 + addend[ao + h], q); }
-            out[oo] = r0;
-            out[oo + h] = r1;
-          }
+            const DsK m = rns_dsk(q, ldc(R.p2q.b_c, l), R.p2q.pw);
+            // this limb's chain stays unreduced until its last product (which takes any 64-bit multiplicand): the same residues
+            lane_gs<true>(x, hi, ldc4(E.inv_n, l), ldc4(E.inv_nw, l), m);  // < q + 9c
+            const u64 vq = x + ldc(R.half_q, l);                            // < 2q + 9c
+            u64 sw;                                                         // < 3q
+            if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
+                sw = vp[0] - __umul64hi(vp[0], ldc(R.red_mu, l)) * q;
+                sw = csub(csub(sw, q), q);
+            } else {
+                sw = base_conv_dot<MAXA, FULL, true, true>(R.p2q, l, vs) + q - sub;
+            }
+            u64 r = csub(ArithDS<60>::mul(vq + (m.q + m.q2) - sw, ldc4(R.pinv_ds, l), m), q);
+            if (ad) r = csub(r + a, q);
+            dst[size_t(l) * n] = r;
         }
     }
 }
