@@ -614,6 +614,15 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     STAMP_FLUSH();
 }
 
+// Which sub-polynomial a workgroup takes.  A launch over several moduli (the RNS limbs of CKKS: polynomial p uses descs[p % n_desc])
+// comes as a 2-D grid, y = the modulus, x = that modulus's sub-polynomials across the batch: workgroups are dispatched x first, so
+// the ~512 that are resident together share a few twiddle tables (768 KiB each at 60 bits) instead of all n_desc of them -- 16
+// tables are 12 MiB against 4 MiB of L2 per XCD.
+__device__ __forceinline__ unsigned sub_of_block(int pb, unsigned n_desc) {
+    if (gridDim.y == 1) return blockIdx.x;
+    return ((((blockIdx.x >> pb) * n_desc) + blockIdx.y) << pb) | (blockIdx.x & ((1u << pb) - 1));
+}
+
 }  // namespace w14
 
 // One workgroup = one (sub-)polynomial.  (A persistent variant -- two workgroups per CU looping over polynomials, the next one's
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_fwd_kernel(u64 *
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const unsigned sub = blockIdx.x;
+    const unsigned sub = w14::sub_of_block(PFX ? pb : 0, n_desc);
     const unsigned poly = PFX ? sub >> pb : sub;
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const unsigned sub = blockIdx.x;
+    const unsigned sub = w14::sub_of_block(PFX ? pb : 0, n_desc);
     const unsigned poly = PFX ? sub >> pb : sub;
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);

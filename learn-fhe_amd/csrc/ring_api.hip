@@ -1,5 +1,6 @@
 // extern "C" entry points declared in include/fhe_ring.h: context set-up and the transform launches.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstring>
 #include <mutex>
@@ -86,12 +87,22 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // workgroups per CU.  AF / AI: the arithmetic policy of each direction (measured, tools/ntt_lab2.hip, 4096 transforms at 60 bits:
 // forward 0.274 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.296 against
 // 0.320 since its first pass runs in diagonal form and nothing spills: ntt14w.hpp).
+inline bool limb_major_disabled() {  // FHE_RING_NO_LIMB_MAJOR=1: A/B switch
+    const char *e = getenv("FHE_RING_NO_LIMB_MAJOR");
+    return e && e[0] == '1';
+}
 template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
                 : (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, false, true, R0> : fhe::ntt14w_inv_kernel<AI, false, false, R0>) : fhe::ntt14w_fwd_kernel<AF, false, R0>);
     HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>()));
-    hipLaunchKernelGGL(k, dim3((unsigned)subs), dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, pb, io);
+    // several moduli: modulus-major dispatch order (ntt14w.hpp, sub_of_block)
+    const size_t polys = subs >> pb;
+    // (only launches of several generations of workgroups: when the whole launch is resident at once the order is irrelevant, and
+    // measured 3 % slower at cfg4 batch 8)
+    const bool by_mod = nd > 1 && nd <= 65535 && polys % nd == 0 && subs >= 2048 && !limb_major_disabled();
+    const dim3 grid = by_mod ? dim3((unsigned)(subs / nd), nd) : dim3((unsigned)subs);
+    hipLaunchKernelGGL(k, grid, dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
     return FHE_OK;
 }

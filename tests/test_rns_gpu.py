@@ -149,6 +149,42 @@ def test_ckks_key_switch_2p15_edge_route(fhe, cref, torch_cuda, big_l, big_k, mo
     assert np.array_equal(host(b)[0], eb) and np.array_equal(host(a)[0], ea)
 
 
+def test_modulus_major_dispatch_large_batches(fhe, cref, torch_cuda, monkeypatch):
+    """Launches over several moduli that span several generations of workgroups are dispatched modulus by modulus (a 2-D grid,
+    ntt14w.hpp `sub_of_block`): N = 2^14 transforms of 512 x 4 limbs against the oracle on a spread sample + round trip on all of
+    them, and a batch-32 key switch at N = 2^15 bit-equal to the linear dispatch order and to the oracle."""
+    n, batch = 1 << 14, 512
+    primes = cref.two_adic_primes(60, 16, 4)
+    qs, ps = primes[:2], primes[2:]
+    rns = fhe.RnsContext(qs, ps)
+    a = rand_limbs(51, qs + ps, n, batch)
+    d = dev(torch_cuda, a)
+    rns.ntt_(d, n, extended=True)
+    got = host(d)
+    for b in (0, 1, 255, 510, 511):
+        for l, q in enumerate(qs + ps):
+            assert np.array_equal(got[b, l], cref.ntt_fwd(q, a[b, l], n)), (b, l)
+    rns.ntt_(d, n, extended=True, inverse=True)
+    assert np.array_equal(host(d), a)
+    # the fused inverse of the key switch (2 x 32 x 4 x 2 = 512 ... x 16 limbs at cfg4's shape = 2048 sub-transforms)
+    g = load_golden("moduli.json")
+    qs, ps = g["cfg4_qs"], g["cfg4_ps"]
+    n, batch = 1 << 15, 32
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(52, qs + ps, n), rand_limbs(53, qs + ps, n)
+    cb, ca = rand_limbs(54, qs, n, batch), rand_limbs(55, qs, n, batch)
+    key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
+    b, a2 = dev(torch_cuda, cb), dev(torch_cuda, ca)
+    key.key_switch_(b, a2)
+    monkeypatch.setenv("FHE_RING_NO_LIMB_MAJOR", "1")
+    b2, a3 = dev(torch_cuda, cb), dev(torch_cuda, ca)
+    key.key_switch_(b2, a3)
+    monkeypatch.delenv("FHE_RING_NO_LIMB_MAJOR")
+    assert np.array_equal(host(b), host(b2)) and np.array_equal(host(a2), host(a3))
+    eb, ea = cref.ckks_key_switch(qs, ps, kb, ka, cb[31], ca[31])
+    assert np.array_equal(host(b)[31], eb) and np.array_equal(host(a2)[31], ea)
+
+
 def test_rns_errors(fhe):
     import ctypes as C
     lib = fhe.lib()
