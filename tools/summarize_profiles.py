@@ -90,7 +90,7 @@ if fw_r and fw_w:
 # per-kernel counters of the secondary workloads (bench.py blocks ntt_mul / fhew / ckks / tfhe): HBM bytes per launch and the
 # wave-cycle split, for the kernels that dominate them
 SECONDARY = ("blind_rotate_kernel", "torus30_blind_rotate_kernel", "external_product_kernel", "ntt14w_fwd_kernel", "ntt14w_inv_kernel", "ntt_big_fwd_pass",
-             "ntt_big_inv_pass", "rns_rescale_kernel", "rns_extend_kernel", "tlwe_key_switch", "lwe_key_switch")
+             "ntt_big_inv_pass", "rns_rescale_kernel", "rns_extend_kernel", "rns_rescale_edge_kernel", "rns_extend_edge_kernel", "tlwe_key_switch", "lwe_key_switch")
 sec = {}
 for k, e in summary.items():
     if not k.startswith("prof_sec"):
