@@ -83,7 +83,22 @@ struct NttIo {
     unsigned src_mod = 1;
     const u64 *mul = nullptr;
     unsigned mul_div = 1, mul_period = 1;
+    // (forward only) up to four separate sources in ONE launch: sub-polynomial s reads from source s / src_group (src, src2, src3,
+    // src4), sub-polynomial s % src_group of it.  Four caller buffers of 128 polynomials each would otherwise be four launches of
+    // 128 workgroups -- half a chip each for the one-workgroup-per-CU kernels.
+    const u64 *src2 = nullptr, *src3 = nullptr, *src4 = nullptr;
+    unsigned src_group = 0;
 };
+// where sub-polynomial `sub` (2^log_len words) is read from; `own` = its place in the launch's buffer
+__device__ __forceinline__ const u64 *ntt_src(const NttIo &io, unsigned sub, int log_len, const u64 *own) {
+    if (!io.src) return own;
+    if (io.src_group) {
+        const unsigned gsel = sub / io.src_group, r = sub - gsel * io.src_group;
+        const u64 *b = gsel == 0 ? io.src : gsel == 1 ? io.src2 : gsel == 2 ? io.src3 : io.src4;
+        return b + (size_t(r) << log_len);
+    }
+    return io.src + (size_t(sub % io.src_mod) << log_len);
+}
 
 struct ArithShoup {
     typedef u64 Elem;  // the integer type a coefficient occupies in registers, LDS and HBM

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_fwd_kernel(u64 *
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
     u64 *g = data + (size_t(sub) << LOG_N);
-    const u64 *gs = io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g;
+    const u64 *gs = ntt_src(io, sub, LOG_N, g);
     u64 x[32];
     w14::load_p0<R0>(x, gs, t);
     w14::fwd_one<A, R0>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w STAMP_ENTRY_ARG);

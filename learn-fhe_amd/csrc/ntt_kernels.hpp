@@ -174,7 +174,7 @@ __global__ __launch_bounds__((NttCfg<LOG_N, LOG_E, PPW>::THREADS)) void ntt_fwd_
     u64 *g = data + size_t(poly) * C::N;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + pw * C::PN;
     u64 x[C::E];
-    fwd_run<A, C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, k, io.src ? io.src + size_t(poly % io.src_mod) * C::N : nullptr);
+    fwd_run<A, C, LOG_N, LOG_E, 0, false, false, DIRECT>(x, t, g, lds, active, k, io.src ? ntt_src(io, active ? poly : 0u, LOG_N, nullptr) : nullptr);
     if constexpr (C::P > 1 && !DIRECT) {
         // the canonical image sits in LDS: stream it out with consecutive lanes on consecutive addresses
         if (active) {

@@ -144,6 +144,7 @@ namespace fhe {
 int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
     if (io.mul) return FHE_ERR_INVALID;  // the pointwise multiplier belongs to the inverse
     if (log_n <= 15) return sub_fwd(descs, n_desc, a, log_n, batch, 0, pm, st, io);
+    if (io.src_group) return FHE_ERR_UNSUPPORTED;  // several sources: single-pass rings only (callers fall back to one launch each)
     const int pb = log_n - 14;
     const size_t cols = batch << 14;
     switch (pb) {  // the opening pass reads the source, everything after it runs in place
@@ -157,6 +158,7 @@ int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size
 }
 
 int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
+    if (io.src_group) return FHE_ERR_INVALID;
     if (log_n <= 15) return sub_inv(descs, n_desc, a, log_n, batch, 0, pm, st, io);
     const int pb = log_n - 14;
     NttIo sub_io = io;  // polynomial counts -> 2^14 block counts

@@ -572,6 +572,11 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
     u64 *e = wsp.as<u64>(), *d = e + 4 * words;
     const u64 *src[4] = {m0.d, m1.d, m2.d, m3.d};
     int rc = FHE_OK;
+    if (n > 1 && log_n <= 15 && batch * L < (size_t(1) << 30)) {  // the four inputs in ONE launch (NttIo::src_group)
+        fhe::NttIo io;
+        io.src = src[0]; io.src2 = src[1]; io.src3 = src[2]; io.src4 = src[3]; io.src_group = (unsigned)(batch * L);
+        rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, e, log_n, 4 * batch * L, st, r->all_pm, io);
+    } else
     for (int i = 0; i < 4 && rc == FHE_OK; ++i) {
         if (n > 1) {
             fhe::NttIo io;
