@@ -1,6 +1,7 @@
 // extern "C" entry points for SURVEY.md section 8(a) rows a8-a13: decomposition, automorphism, monomial
 // multiply, prepared gadget keys, external product, RLWE key switch, LMKCDEY blind rotation.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <new>
 #include <vector>
@@ -146,10 +147,21 @@ int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uin
     return FHE_OK;
 }
 
-// Batches up to this size run the 4-coefficients-per-lane instantiation at N >= 1024 (4 / 8 waves per ciphertext): measured at
-// cfg3 +57 % at batch 1 and 64 (120 vs 77, 7.6 k vs 4.8 k blind rotations/s), -2 % at batch 1024 where the GPU is full either way
+// Which instantiation a batch runs at N >= 1024: 8 coefficients per lane (2 / 4 waves per ciphertext, 250 registers: 2 waves per SIMD,
+// FOUR ciphertexts per CU) or 4 per lane (4 / 8 waves per ciphertext, 148 registers: 3 waves per SIMD, THREE ciphertexts per CU, but 12
+// resident waves instead of 8).  Measured at cfg3 (tools/fhew_shape_lab.py, blind rotations/s, 8-per-lane | 4-per-lane):
+//   batch 1: 77 | 120     64: 4.8 k | 7.6 k     768: 53.0 k | 64.3 k     1024: 66.3 k | 59.0 k     1536: 51.2 k | 68.1 k
+//   2048: 67.7 k | 69.5 k     3072: 67.7 k | 72.2 k     4096: 68.2 k | 73.0 k
+// The 4-per-lane form is the faster kernel per ciphertext (more waves to hide the key-row and LDS latencies behind); the
+// 8-per-lane form wins only where its larger generation (1024 ciphertexts on 256 CUs against 768) saves a whole pass: batches of
+// 769 .. 1024.  (N = 2048 keeps the rule it was measured with: 4 per lane up to 512.)
 constexpr size_t FHEW_SMALL_BATCH = 512;
-inline bool small_shape(int log_n, size_t batch) { return log_n >= 10 && batch <= FHEW_SMALL_BATCH; }
+inline bool small_shape(int log_n, size_t batch) {
+    static const long lab = [] { const char *e = getenv("FHE_RING_SMALL_BATCH"); return e ? atol(e) : -1L; }();  // lab override
+    if (lab >= 0) return log_n >= 10 && batch <= (size_t)lab;
+    if (log_n == 10) return batch <= 768 || batch > 1024;
+    return log_n >= 10 && batch <= FHEW_SMALL_BATCH;
+}
 
 fhe::FhewKey key_view(const fhe_key *k, bool small = false) {
     fhe::FhewKey v;

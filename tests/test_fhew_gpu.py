@@ -208,8 +208,8 @@ def _make_bk(fhe, torch_cuda, q, n, log_b, d, ks_log_b, ks_d, w, n_lwe, seed):
 @pytest.mark.parametrize("q,log_n", [(18014398509404161, 10), (18014398509404161, 11), (35184372060161, 10), (35184372060161, 11)])
 def test_throughput_and_small_batch_shapes_agree(fhe, cref, torch_cuda, q, log_n):
     """N >= 1024 has two instantiations of the fused kernels (8 coefficients per lane above 512 ciphertexts, 4 below, each with
-    its own key layout): the same ciphertext must come out bit-identical from both, and equal to the oracle"""
-    n, lb, d, w, n_lwe, big = 1 << log_n, 6, 3, 3, 3, 516
+    its own key layout; at N = 1024 the 8-per-lane form serves batches of 769 .. 1024 only, fhew_api.hip `small_shape`): the same ciphertext must come out bit-identical from both, and equal to the oracle"""
+    n, lb, d, w, n_lwe, big = 1 << log_n, 6, 3, 3, 3, 800  # 769 .. 1024: the batches that run the 8-per-lane form at N = 1024
     assert cref.is_prime(q) and (q - 1) % (2 * n) == 0
     ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, 5, 4, w, n_lwe, seed=90 + log_n)
     gk, ga = bk.brk, bk.ak
@@ -241,10 +241,12 @@ def test_throughput_and_small_batch_shapes_agree(fhe, cref, torch_cuda, q, log_n
     assert np.array_equal(host(oa)[big - 1], ea) and np.array_equal(host(ob)[big - 1], eb)
 
 
-def test_blind_rotate_large_batch_is_deterministic(fhe, cref, torch_cuda):
-    """cfg3 ring, 1024 ciphertexts (every SIMD busy with two-wave teams sharing LDS images): two runs agree bit for bit, a
-    sample agrees with the small-batch instantiation and one ciphertext with the oracle"""
-    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 1024, 6, 9, 10, 24, 1024
+@pytest.mark.parametrize("batch", [1024, 1600])
+def test_blind_rotate_large_batch_is_deterministic(fhe, cref, torch_cuda, batch):
+    """cfg3 ring, 1024 ciphertexts (every SIMD busy with two-wave teams sharing LDS images) and 1600 (the 4-per-lane form over
+    several generations of workgroups): two runs agree bit for bit, a sample agrees with the small-batch instantiation and one
+    ciphertext with the oracle"""
+    q, n, lb, d, w, n_lwe = 18014398509404161, 1024, 6, 9, 10, 24
     ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, lb, d, w, n_lwe, seed=110)
     rng = np.random.Generator(np.random.PCG64(111))
     lwe_a = (rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
@@ -254,7 +256,7 @@ def test_blind_rotate_large_batch_is_deterministic(fhe, cref, torch_cuda):
     o1 = bk.blind_rotate(da, db, df)
     o2 = bk.blind_rotate(da, db, df)
     assert torch_cuda.equal(o1[0], o2[0]) and torch_cuda.equal(o1[1], o2[1])
-    pick = [0, 511, 1023]
+    pick = [0, 511, batch - 1]
     s = bk.blind_rotate(dev(torch_cuda, lwe_a[pick]), dev(torch_cuda, lwe_b[pick]), df)
     assert np.array_equal(host(o1[0])[pick], host(s[0])) and np.array_equal(host(o1[1])[pick], host(s[1]))
     ea, eb = cref.blind_rotate(q, n, w, lb, d, lb, d, brk, ak, ts, f, lwe_a[777], int(lwe_b[777]))
