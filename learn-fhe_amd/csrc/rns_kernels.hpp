@@ -116,6 +116,19 @@ __global__ void rns_extend_kernel(const u64 *__restrict__ in, size_t in_bs, u64 
                 if (FULL || l < C.la) copy[p * copy_bs + size_t(l) * n + i] = v[l];
         }
         const int u = base_conv_prepare<MAXA, FULL, DS>(C, v, vs);
+        if constexpr (DS) {  // rolled over the output limbs, the table entry one limb ahead: see the edge kernels below
+            const u64 *ua = C.ua + u;
+            const int la = FULL ? MAXA : C.la;
+            u64 nsub = ua[0];
+#pragma unroll 1
+            for (int j = 0; j < C.lb; ++j) {
+                const u64 sub = nsub;
+                if (j + 1 < C.lb) nsub = ua[(j + 1) * (la + 1)];
+                const u64 b = ldc(C.b_mod, j), d = base_conv_dot<MAXA, FULL, true>(C, j, vs);
+                out[p * out_bs + size_t(j) * n + i] = d >= sub ? d - sub : d + b - sub;
+            }
+            continue;
+        }
         // output limbs in independent chains of up to MAXA at a time (the bound that serves the source base serves the target
         // base of the BASELINE shapes too): the unrolled bodies give the scheduler eight dot products to interleave
         for (int j0 = 0; j0 < C.lb; j0 += MAXA) {
@@ -166,6 +179,35 @@ __global__ void rns_rescale_kernel(const u64 *__restrict__ in, size_t in_bs, u64
         for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < R.K) ? csub(in[p * in_bs + size_t(R.L + j) * n + i] + ldc(R.half_p, j), ldc(R.p_mod, j)) : 0;
         int u = 0;
         if (R.K > 1) u = base_conv_prepare<MAXA, FULL, DS>(R.p2q, vp, vs);
+        if constexpr (DS) {  // rolled over the q-limbs, memory operands one limb ahead, the limb's chain unreduced: see the edge kernels
+            const u64 *src = in + p * in_bs + i, *ad = addend ? addend + p * add_bs + i : nullptr;
+            const u64 *ua = R.p2q.ua + u;
+            const int la = FULL ? MAXA : R.p2q.la;
+            u64 nx = src[0], na = ad ? ad[0] : 0, nsub = R.K > 1 ? ua[0] : 0;
+#pragma unroll 1
+            for (int l = 0; l < R.L; ++l) {
+                const u64 x = nx, a = na, sub = nsub;
+                if (l + 1 < R.L) {
+                    nx = src[size_t(l + 1) * n];
+                    if (ad) na = ad[size_t(l + 1) * n];
+                    if (R.K > 1) nsub = ua[(l + 1) * (la + 1)];
+                }
+                const u64 q = ldc(R.q_mod, l);
+                const DsK m = rns_dsk(q, ldc(R.p2q.b_c, l), R.p2q.pw);
+                const u64 vq = x + ldc(R.half_q, l);  // < 2q
+                u64 sw;                               // < 3q
+                if (R.K == 1) {  // rns.rs:108-111: `*vq -= vp.to_u64()` -> vp % q_i
+                    sw = vp[0] - __umul64hi(vp[0], ldc(R.red_mu, l)) * q;
+                    sw = csub(csub(sw, q), q);
+                } else {
+                    sw = base_conv_dot<MAXA, FULL, true, true>(R.p2q, l, vs) + q - sub;
+                }
+                u64 r = csub(ArithDS<60>::mul(vq + (m.q + m.q2) - sw, ldc4(R.pinv_ds, l), m), q);
+                if (ad) r = csub(r + a, q);
+                out[p * out_bs + size_t(l) * n + i] = r;
+            }
+            continue;
+        }
         for (int l0 = 0; l0 < R.L; l0 += MAXA) {
 #pragma unroll
           for (int ll = 0; ll < MAXA; ++ll) {
