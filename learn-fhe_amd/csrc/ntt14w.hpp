@@ -30,7 +30,8 @@
 namespace fhe {
 namespace w14 {
 
-// R0 = layers of pass 0 = log2 of the waves per workgroup: 3 -> N = 2^14 (512 threads, two workgroups per CU), 4 -> N = 2^15
+// R0 = layers of pass 0 = log2 of the waves per workgroup: 1 / 2 -> N = 2^12 / 2^13 (128 / 256 threads, eight / four workgroups per
+// CU), 3 -> N = 2^14 (512 threads, two workgroups per CU), 4 -> N = 2^15
 // (1024 threads, one workgroup per CU, 136 KiB of LDS: a 2^15 ring in ONE pass over HBM instead of a radix-2 pass + two 2^14
 // sub-transforms).  Everything after X01 is the same code: a wave and its 2^11 block.
 constexpr int WSLOTS = 1088;                         // wave-private region: 1024 coefficients + padding, in u64 slots
@@ -345,15 +346,21 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
     STAMP(0);
     {   // pass 0: layers 0..R0-1, twiddles wave-uniform
         Tw a0[1], a1[2], a2[4], a3[8];
-        tw_load<A, false, P0<R0, 0>>(a0, 0, k); tw_load<A, false, P0<R0, 1>>(a1, 0, k); tw_load<A, false, P0<R0, 2>>(a2, 0, k);
+        tw_load<A, false, P0<R0, 0>>(a0, 0, k);
+        if constexpr (R0 >= 2) tw_load<A, false, P0<R0, (R0 >= 2 ? 1 : 0)>>(a1, 0, k);
+        if constexpr (R0 >= 3) tw_load<A, false, P0<R0, (R0 >= 3 ? 2 : 0)>>(a2, 0, k);
         if constexpr (R0 == 4) tw_load<A, false, P0<R0, (R0 == 4 ? 3 : 0)>>(a3, 0, k);
         STAMP(1);
         FHE_SCHED_FENCE();
         ct_apply<A, P0<R0, 0>>(x, a0, k);
-        FHE_SCHED_FENCE();
-        ct_apply<A, P0<R0, 1>>(x, a1, k);
-        FHE_SCHED_FENCE();
-        ct_apply<A, P0<R0, 2>>(x, a2, k);
+        if constexpr (R0 >= 2) {
+            FHE_SCHED_FENCE();
+            ct_apply<A, P0<R0, (R0 >= 2 ? 1 : 0)>>(x, a1, k);
+        }
+        if constexpr (R0 >= 3) {
+            FHE_SCHED_FENCE();
+            ct_apply<A, P0<R0, (R0 >= 3 ? 2 : 0)>>(x, a2, k);
+        }
         if constexpr (R0 == 4) {
             FHE_SCHED_FENCE();
             ct_apply<A, P0<R0, (R0 == 4 ? 3 : 0)>>(x, a3, k);
@@ -574,7 +581,8 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
     STAMP(5);
     Tw a3[8], a2[4], a1[2], a0[1];
     if constexpr (R0 == 4) tw_load<A, true, P0<R0, (R0 == 4 ? 3 : 0)>>(a3, 0, k);
-    tw_load<A, true, P0<R0, 2>>(a2, 0, k); tw_load<A, true, P0<R0, 1>>(a1, 0, k);
+    if constexpr (R0 >= 3) tw_load<A, true, P0<R0, (R0 >= 3 ? 2 : 0)>>(a2, 0, k);
+    if constexpr (R0 >= 2) tw_load<A, true, P0<R0, (R0 >= 2 ? 1 : 0)>>(a1, 0, k);
     if constexpr (PFX) tw_load<A, true, P0<R0, 0>>(a0, 0, k);
     xchg_10<R0>(x, t, w, lds);
     STAMP(6);
@@ -582,22 +590,26 @@ __device__ __forceinline__ void inv_one(u64 (&x)[32], Tw7<A> (&d)[2], u64 *__res
         FHE_SCHED_FENCE();
         gs_apply<A, P0<R0, (R0 == 4 ? 3 : 0)>, 11>(x, a3, k);
     }
-    FHE_SCHED_FENCE();
-    gs_apply<A, P0<R0, 2>, 8 + R0>(x, a2, k);
-    FHE_SCHED_FENCE();
-    gs_apply<A, P0<R0, 1>, 9 + R0>(x, a1, k);
+    if constexpr (R0 >= 3) {
+        FHE_SCHED_FENCE();
+        gs_apply<A, P0<R0, (R0 >= 3 ? 2 : 0)>, 8 + R0>(x, a2, k);
+    }
+    if constexpr (R0 >= 2) {
+        FHE_SCHED_FENCE();
+        gs_apply<A, P0<R0, (R0 >= 2 ? 1 : 0)>, 9 + R0>(x, a1, k);
+    }
     // the last layer leaves canonical values: a whole ring folds n^-1 into it (the difference branch multiplies by twi[1] n^-1),
     // a sub-transform of a larger ring is not scaled here at all
     STAMP(7);
     typename A::TwReg wlast{};
     if constexpr (PFX) wlast = A::prep(a0[0]);
     constexpr int LAST_PH = A::GS_SPAN > 0 ? (10 + R0) % (A::GS_SPAN > 0 ? A::GS_SPAN : 1) : 1;  // layers since the sums were last folded
-    constexpr int HALF = 1 << (R0 - 1), REPS = 32 >> R0;
-    static_for<0, REPS * (HALF / 4)>([&](auto cc) {  // four butterflies at a time, stored as they finish
-        constexpr int pass = decltype(cc)::value / (HALF / 4), j0 = (decltype(cc)::value % (HALF / 4)) * 4;
+    constexpr int HALF = 1 << (R0 - 1), REPS = 32 >> R0, CH = HALF < 4 ? HALF : 4;
+    static_for<0, REPS * (HALF / CH)>([&](auto cc) {  // (up to) four butterflies at a time, stored as they finish
+        constexpr int pass = decltype(cc)::value / (HALF / CH), j0 = (decltype(cc)::value % (HALF / CH)) * CH;
         FHE_SCHED_FENCE();
 #pragma unroll
-        for (int j = j0; j < j0 + 4; ++j) {
+        for (int j = j0; j < j0 + CH; ++j) {
             const int o = (pass << R0) + j;
             if constexpr (PFX) A::template gs_last_plain<LAST_PH>(x[o], x[o + HALF], wlast, k);
             else A::template gs_last_scaled<LAST_PH>(x[o], x[o + HALF], k);

@@ -91,6 +91,10 @@ inline bool limb_major_disabled() {  // FHE_RING_NO_LIMB_MAJOR=1: A/B switch
     const char *e = getenv("FHE_RING_NO_LIMB_MAJOR");
     return e && e[0] == '1';
 }
+inline bool wave_local_small_disabled() {  // FHE_RING_NO_W12=1: A/B switch (2^12 / 2^13 on the generic kernels)
+    const char *e = getenv("FHE_RING_NO_W12");
+    return e && e[0] == '1';
+}
 template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
@@ -114,6 +118,16 @@ int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_
         if (pm == 60) return launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 4>(inv, d, nd, a, subs, 0, st, io);
         if (pm == 54) return launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 4>(inv, d, nd, a, subs, 0, st, io);
         return launch14<fhe::ArithShoup, fhe::ArithShoup, 4>(inv, d, nd, a, subs, 0, st, io);
+    }
+    if ((log_n == 12 || log_n == 13) && !wave_local_small_disabled()) {
+        // 2^12 / 2^13 rings in the wave-local form as well (R0 = 1 / 2: two / four waves, each owning a 2^11 block; eight / four
+        // workgroups per CU): at 60 bits forward 3.3 -> 4.0 and 2.8 -> 4.1 TB/s, inverse 2.9 -> 4.2 and 2.5 -> 3.9
+        if (pm == 60) return log_n == 13 ? launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 2>(inv, d, nd, a, subs, 0, st, io)
+                                         : launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 1>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 54) return log_n == 13 ? launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 2>(inv, d, nd, a, subs, 0, st, io)
+                                         : launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 1>(inv, d, nd, a, subs, 0, st, io);
+        return log_n == 13 ? launch14<fhe::ArithShoup, fhe::ArithShoup, 2>(inv, d, nd, a, subs, 0, st, io)
+                           : launch14<fhe::ArithShoup, fhe::ArithShoup, 1>(inv, d, nd, a, subs, 0, st, io);
     }
     if (log_n < 10) return dispatch_small<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, st, io);
     if (pm == 60) return log_n == 14 ? launch14<fhe::ArithDS<60>, fhe::ArithDS<60>>(inv, d, nd, a, subs, pb, st, io)
