@@ -91,8 +91,8 @@ def ntt_mul_bench(torch, F, dev, local_rank, batch, reps=20):
     b = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
     dt = _timeit(torch, lambda: ctx.mul_(a, b, n), reps)
     out = {"workload": "ring product a *= b, N=2^14, q=%d, batch=%d" % (Q, batch), "products_per_sec": batch / dt,
-           "hbm_traffic_bytes_per_product_by_construction": 56 * n}
-    out["roofline"] = roof(batch / dt, 24 * n, "ntt14w_fwd_kernel x2 + ntt14w_inv_kernel (pointwise product fused into its load)")
+           "hbm_traffic_bytes_per_product_by_construction": 40 * n}
+    out["roofline"] = roof(batch / dt, 24 * n, "ntt14w_fwd_kernel (right operand, out of place) + ntt14w_mul_kernel (forward of the left operand, pointwise product, inverse: one workgroup, one load and one store)")
     return out
 
 

@@ -40,6 +40,8 @@ int ctx_build_host(uint64_t q, fhe_ctx *c);  // returns FHE_* status
 // io (arith.hpp NttIo): optional out-of-place source / fused pointwise multiplier, indices in POLYNOMIALS of this launch
 int ntt_fwd_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0, NttIo io = NttIo());
 int ntt_inv_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm = 0, NttIo io = NttIo());
+// a <- inverse(forward(a) (.) io.mul): one fused launch at 2^13 .. 2^15, forward + multiplying inverse otherwise
+int ntt_mul_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io);
 // 2^15 rings without their outermost layer (two independent 2^14 sub-transforms per polynomial): see ring_api.hip
 int ntt_fwd_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch, hipStream_t st, int pm, NttIo io = NttIo());
 int ntt_inv_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch, hipStream_t st, int pm, NttIo io = NttIo());

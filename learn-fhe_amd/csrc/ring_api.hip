@@ -111,6 +111,27 @@ int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, 
     return FHE_OK;
 }
 
+// the fused ring product (ntt14w_mul_kernel): a <- inverse(forward(a) (.) io.mul), 2^13 .. 2^15
+template <class A, int R0>
+int launch_mul14(const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, hipStream_t st, fhe::NttIo io) {
+    auto k = fhe::ntt14w_mul_kernel<A, R0>;
+    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>()));
+    const bool by_mod = nd > 1 && nd <= 65535 && subs % nd == 0 && subs >= 2048 && !limb_major_disabled();
+    const dim3 grid = by_mod ? dim3((unsigned)(subs / nd), nd) : dim3((unsigned)subs);
+    hipLaunchKernelGGL(k, grid, dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, 0, io);
+    HIP_TRY(hipGetLastError());
+    return FHE_OK;
+}
+template <class A>
+int dispatch_mul14(int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, hipStream_t st, fhe::NttIo io) {
+    switch (log_n) {
+        case 13: return launch_mul14<A, 2>(d, nd, a, subs, st, io);
+        case 14: return launch_mul14<A, 3>(d, nd, a, subs, st, io);
+        case 15: return launch_mul14<A, 4>(d, nd, a, subs, st, io);
+        default: return FHE_ERR_UNSUPPORTED;
+    }
+}
+
 // pm = common bit length of pseudo-Mersenne eligible moduli for which kernels are instantiated (60, 54), else 0
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
@@ -201,6 +222,20 @@ int ntt_fwd_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch,
 int ntt_inv_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch, hipStream_t st, int pm, NttIo io) {
     io.src_mod <<= 1; io.mul_div <<= 1; io.mul_period <<= 1;
     return sub_inv(descs, n_desc, a, 14, batch << 1, 1, pm, st, io);
+}
+
+// a[s] <- inverse(forward(a[s]) (.) io.mul[..]) in one launch where a fused kernel exists (2^13 .. 2^15), else forward + inverse
+// with the product on the inverse's load.  io.mul as for ntt_inv_multi; io.src must be null.
+int ntt_mul_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
+    if (!io.mul || io.src) return FHE_ERR_INVALID;
+    static const bool off = [] { const char *e = getenv("FHE_RING_NO_FUSED_MUL"); return e && e[0] == '1'; }();
+    if (log_n >= 13 && log_n <= 15 && !off) {
+        if (pm == 60) return dispatch_mul14<ArithDS<60>>(log_n, descs, n_desc, a, batch, st, io);
+        if (pm == 54) return dispatch_mul14<ArithDS<54>>(log_n, descs, n_desc, a, batch, st, io);
+        return dispatch_mul14<ArithShoup>(log_n, descs, n_desc, a, batch, st, io);
+    }
+    int rc = ntt_fwd_multi(descs, n_desc, a, log_n, batch, st, pm);
+    return rc != FHE_OK ? rc : ntt_inv_multi(descs, n_desc, a, log_n, batch, st, pm, io);
 }
 
 int ntt_fwd_device(const fhe_ctx *c, u64 *a, int log_n, size_t batch, hipStream_t st) { return ntt_fwd_multi(c->d_desc, 1, a, log_n, batch, st, c->pm_b); }
@@ -506,11 +541,10 @@ int fhe_ntt_mul(const fhe_ctx *ctx, uint64_t *a, const uint64_t *b, size_t n, si
         rc = hipMemcpyAsync(tb, b, count * sizeof(u64), kind, st) == hipSuccess ? FHE_OK : FHE_ERR_HIP;
         if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, tb, log_n, batch, st);
     }
-    if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_device(ctx, ma.d, log_n, batch, st);
-    if (rc == FHE_OK && n > 1) {
+    if (rc == FHE_OK && n > 1) {  // forward of a, product, inverse: one launch at 2^13 .. 2^15 (ntt14w_mul_kernel: 40 N bytes in all)
         fhe::NttIo mul_b;
         mul_b.mul = tb; mul_b.mul_div = (unsigned)batch; mul_b.mul_period = (unsigned)batch;
-        rc = fhe::ntt_inv_multi(ctx->d_desc, 1, ma.d, log_n, batch, st, ctx->pm_b, mul_b);
+        rc = fhe::ntt_mul_multi(ctx->d_desc, 1, ma.d, log_n, batch, st, ctx->pm_b, mul_b);
     } else if (rc == FHE_OK) {
         rc = launch_pointwise(ctx, ma.d, tb, count, st);  // n = 1: `a[0] *= b[0]`
     }
