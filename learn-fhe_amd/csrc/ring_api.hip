@@ -228,7 +228,8 @@ int ntt_inv_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch,
 // with the product on the inverse's load.  io.mul as for ntt_inv_multi; io.src must be null.
 int ntt_mul_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
     if (!io.mul || io.src) return FHE_ERR_INVALID;
-    static const bool off = [] { const char *e = getenv("FHE_RING_NO_FUSED_MUL"); return e && e[0] == '1'; }();
+    const char *env = getenv("FHE_RING_NO_FUSED_MUL");  // A/B switch, read per call (the tests toggle it)
+    const bool off = env && env[0] == '1';
     if (log_n >= 13 && log_n <= 15 && !off) {
         if (pm == 60) return dispatch_mul14<ArithDS<60>>(log_n, descs, n_desc, a, batch, st, io);
         if (pm == 54) return dispatch_mul14<ArithDS<54>>(log_n, descs, n_desc, a, batch, st, io);

@@ -274,3 +274,35 @@ def test_scratch_pool_is_private_and_trimmable(fhe, torch_cuda):
     torch_cuda.cuda.synchronize()
     assert hip.hipMemPoolGetAttribute(pool, HIP_MEMPOOL_ATTR_RELEASE_THRESHOLD, C.byref(thr)) == 0 and thr.value == before
     assert fhe.lib().fhe_trim() == 0
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15])
+def test_alternative_routes_agree(fhe, cref, torch_cuda, log_n, monkeypatch):
+    """2^12 / 2^13 rings run the wave-local kernels (R0 = 1 / 2) and ring products at 2^13 .. 2^15 the fused forward-multiply-inverse
+    kernel; the library keeps the older routes behind environment switches: both must give the same bits, and the oracle's."""
+    import torch
+    n, batch = 1 << log_n, 5
+    for q in (cref.two_adic_primes(60, 17, 1)[0], cref.two_adic_primes(54, 17, 1)[0], cref.two_adic_primes(45, 17, 1)[0]):  # two-operand products at 60 bits; Shoup
+        rng = np.random.Generator(np.random.PCG64(log_n))
+        a = rng.integers(0, q, size=(batch, n), dtype=np.uint64)
+        b = rng.integers(0, q, size=(batch, n), dtype=np.uint64)
+        a[0, :] = q - 1
+        b[0, :] = q - 1
+        ctx = fhe.NttContext(q)
+        outs = []
+        for env in ({}, {"FHE_RING_NO_W12": "1", "FHE_RING_NO_FUSED_MUL": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            f = torch.from_numpy(a.view(np.int64)).cuda()
+            ctx.ntt_(f, n)
+            m = torch.from_numpy(a.view(np.int64)).cuda()
+            ctx.mul_(m, torch.from_numpy(b.view(np.int64)).cuda(), n)
+            r = f.clone()
+            ctx.intt_(r, n)
+            outs.append((f.cpu().numpy().view(np.uint64), m.cpu().numpy().view(np.uint64), r.cpu().numpy().view(np.uint64)))
+            for k in env:
+                monkeypatch.delenv(k)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][2], a) and np.array_equal(outs[1][2], a)
+        assert np.array_equal(outs[0][0][1], cref.ntt_fwd(q, a[1], n))
+        assert np.array_equal(outs[0][1][0], cref.ntt_mul(q, a[0], b[0], n))
