@@ -337,11 +337,10 @@ __device__ __forceinline__ void store_p3(u64 (&x)[32], u64 *__restrict__ dst_wav
 }
 
 // One forward transform.  x[] arrives loaded (pass-0 layout, the loads possibly still in flight).
-// KEEP: nothing is stored -- every finished replica is canonicalised and multiplied by the evaluations at `mulp` (this lane's place
-// in a second operand, pass-3 layout: exactly what the inverse loads), and x[] leaves as the inverse transform's input.
+// KEEP: nothing is stored -- every finished replica is left canonical in the pass-3 layout, exactly what the inverse transform loads.
 template <class A, int R0, bool KEEP = false>
 __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const typename A::K &k, u64 *lds, u64 *wl,
-                                        const int t, const int lane, const int w STAMP_ENTRY_PARAM, const u64 *__restrict__ mulp = nullptr) {
+                                        const int t, const int lane, const int w STAMP_ENTRY_PARAM) {
     typedef typename A::TwRaw Tw;
     STAMP_DECL;
     STAMP_REAL(10);
@@ -417,33 +416,22 @@ __device__ __forceinline__ void fwd_one(u64 (&x)[32], u64 *__restrict__ g, const
         for (int r = 0; r < 32; ++r) x[r] = A::fold(x[r], k);
     }
     u64 *dst_wave = g + (w << 11);
-    ulonglong2 mv[4];  // KEEP: one replica's multipliers, requested when the replica's last layer is done and used one replica later
-    auto keep_mul = [&](auto abc) {
-        constexpr int ab = decltype(abc)::value;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[ab * 8 + 2 * j] = A::mulvar(A::canon_fwd(x[ab * 8 + 2 * j], k), mv[j].x, k);
-            x[ab * 8 + 2 * j + 1] = A::mulvar(A::canon_fwd(x[ab * 8 + 2 * j + 1], k), mv[j].y, k);
-        }
-    };
     static_for<0, 4>([&](auto abc) {
         constexpr int ab = decltype(abc)::value;
         FHE_SCHED_FENCE();
         ct_apply<A, P3<R0, 0, ab>>(x, d[ab & 1].l0, k);
         ct_apply<A, P3<R0, 1, ab>>(x, d[ab & 1].l1, k);
-        if constexpr (KEEP && ab > 0) keep_mul(std::integral_constant<int, (ab > 0 ? ab - 1 : 0)>{});
         FHE_SCHED_FENCE();
         if constexpr (ab < 3) tw7_load<A, false, R0, (ab < 3 ? ab + 1 : 3)>(d[(ab + 1) & 1], t3, k);
         ct_apply<A, P3<R0, 2, ab>>(x, d[ab & 1].l2, k);
         FHE_SCHED_FENCE();
         if constexpr (KEEP) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mv[j] = *reinterpret_cast<const ulonglong2 *>(mulp + (ab << 9) + 2 * j);
+            for (int j = 0; j < 8; ++j) x[ab * 8 + j] = A::canon_fwd(x[ab * 8 + j], k);
         } else {
             store_p3<A, ab>(x, dst_wave, lane, wl, k);
         }
     });
-    if constexpr (KEEP) keep_mul(std::integral_constant<int, 3>{});
     STAMP(8);
 #ifdef NTT14_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic builds only: when have the stores left?
@@ -728,15 +716,31 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_mul_kernel(u64 *
     const ModDesc &D = descs[n_desc == 1 ? 0 : sub % n_desc];
     const typename A::K k = A::make(D, LOG_N, 0, 0);
     u64 *g = data + (size_t(sub) << LOG_N);
-    const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << LOG_N) + ((w << 11) | (lane << 3));
+    const u64 *mul_poly = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << LOG_N);  // wave uniform
     u64 x[32];
     w14::load_p0<R0>(x, g, t);
-    w14::fwd_one<A, R0, true>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w STAMP_ENTRY_ARG, mul);
+    w14::fwd_one<A, R0, true>(x, g, k, lds, lds + w * w14::WSLOTS, t, lane, w STAMP_ENTRY_ARG);
     // the inverse half sees the thread index as a fresh value: its ~100 addresses (LDS slots, twiddle entries, stores) would otherwise
     // be computed at the top of the kernel and live -- spilled -- through the whole forward half
     int ti = t;
     asm volatile("" : "+v"(ti));
     const int lane_i = ti & 63, wi = __builtin_amdgcn_readfirstlane(ti >> 6);
+    {   // util/src/ring/fft/zq.rs:17 `a[i] *= b[i]`, two replicas at a time (their multipliers: 32 registers beside the 64 of x)
+        const u64 *mp = mul_poly + ((wi << 11) | (lane_i << 3));
+        static_for<0, 2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            ulonglong2 mv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) mv[r] = *reinterpret_cast<const ulonglong2 *>(mp + ((2 * h + (r >> 2)) << 9) + 2 * (r & 3));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int o = (2 * h + (r >> 2)) * 8 + 2 * (r & 3);
+                x[o] = A::mulvar(x[o], mv[r].x, k);
+                x[o + 1] = A::mulvar(x[o + 1], mv[r].y, k);
+            }
+            FHE_SCHED_FENCE();
+        });
+    }
     w14::Tw7<A> d[2];
     if constexpr (w14::w14_p3_diag<A>()) w14::p3_diag_load<A, R0, 0>(reinterpret_cast<uint4(&)[7]>(d[0]), (wi << 8) | lane_i, k);
     else w14::tw7_load<A, true, R0, 0>(d[0], (wi << 8) | lane_i, k);
