@@ -684,15 +684,23 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     u64 *g = data + (size_t(sub) << LOG_N);
     u64 x[32];
     w14::Tw7<A> d[2];
-    if constexpr (w14::w14_p3_diag<A>()) w14::p3_diag_load<A, R0, 0>(reinterpret_cast<uint4(&)[7]>(d[0]), (w << 8) | lane, k);
-    else w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
-    if constexpr (!w14::w14_p3_diag<A>() && !w14::w14_p3_refill<A>()) w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
+    auto load_first_twiddles = [&]() {
+        if constexpr (w14::w14_p3_diag<A>()) w14::p3_diag_load<A, R0, 0>(reinterpret_cast<uint4(&)[7]>(d[0]), (w << 8) | lane, k);
+        else w14::tw7_load<A, true, R0, 0>(d[0], (w << 8) | lane, k);
+        if constexpr (!w14::w14_p3_diag<A>() && !w14::w14_p3_refill<A>()) w14::tw7_load<A, true, R0, 1>(d[1], (w << 8) | lane, k);
+    };
+    // plain transform: twiddles BEFORE coefficients (vmcnt retires in order, the twiddles are L2 hits).  With a multiplier the
+    // coefficients and their multipliers come first (two 64-register sets in flight) and the first twiddles are requested behind the
+    // products: held across them they are the registers that spill (4-5 per lane, 20 bytes of scratch traffic per lane)
+    if constexpr (!MUL) load_first_twiddles();
     const int off = (w << 11) | (lane << 3);
     const u64 *src = (io.src ? io.src + (size_t(sub % io.src_mod) << LOG_N) : g) + off;
     if constexpr (MUL) {
         const u64 *mul = io.mul + ((size_t(sub / io.mul_div) * io.mul_period + sub % io.mul_period) << LOG_N) + off;
         w14::load_mul_p3<A, 0>(x, src, mul, k); w14::load_mul_p3<A, 1>(x, src, mul, k);
         w14::load_mul_p3<A, 2>(x, src, mul, k); w14::load_mul_p3<A, 3>(x, src, mul, k);
+        FHE_SCHED_FENCE();
+        load_first_twiddles();
     } else {
         w14::load_p3<0>(x, src); w14::load_p3<1>(x, src); w14::load_p3<2>(x, src); w14::load_p3<3>(x, src);
     }
