@@ -104,14 +104,14 @@ struct ArithShoup {
     typedef u64 Elem;  // the integer type a coefficient occupies in registers, LDS and HBM
     struct K {
         u64 q, q2;
-        const FHE_GLOBAL TwPair *tw, *twi;
+        const FHE_CONST TwPair *tw, *twi;  // constant address space: wave-uniform entries become scalar loads (as in the other policies)
         u64 ninv, ninv_s;
         int pb, prefix;
         TwPair ninv_w;  // n^-1 * twi[1] (whole rings only, pb = 0)
         Barrett bar;
     };
     static __device__ __forceinline__ K make(const ModDesc &D, int log_n_total, int pb, int prefix) {
-        return K{D.q, 2 * D.q, as_global(D.tw), as_global(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix,
+        return K{D.q, 2 * D.q, as_const(D.tw), as_const(D.twi), pb ? 1 : D.ninv[log_n_total], pb ? D.one_s : D.ninv_s[log_n_total], pb, prefix,
                  TwPair{D.ninv_w[log_n_total], D.ninv_w_s[log_n_total]}, Barrett{D.q, D.bar_mu, D.bar_sh1, D.bar_sh2}};
     }
     // x y mod q for two canonical variable operands (fused pointwise products): canonical
@@ -136,7 +136,7 @@ struct ArithShoup {
     static constexpr int PREFETCH = 0;  // largest twiddle set fetched one unit ahead (ntt14.hpp); 16-byte raw twiddles: none fits
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
-        const FHE_GLOBAL TwPair *p = (INV ? k.twi : k.tw) + idx;
+        const FHE_CONST TwPair *p = (INV ? k.twi : k.tw) + idx;
         TwRaw r;
         r.w = p->w; r.ws = p->ws;
         return r;
