@@ -33,16 +33,16 @@ struct Arith30 {
     static __device__ constexpr bool ct_fold_at(int) { return false; }
     struct K {
         unsigned p, p2;
-        const FHE_GLOBAL uint2 *tw, *twi;
+        const FHE_CONST uint2 *tw, *twi;  // constant address space: wave-uniform entries become scalar loads
         unsigned ninv, ninv_s, pinv_neg;
         int pb, prefix;
     };
     static __device__ __forceinline__ K make(const Mod30Desc &D, int log_n) {
-        return K{D.p, 2 * D.p, (const FHE_GLOBAL uint2 *)D.tw, (const FHE_GLOBAL uint2 *)D.twi, D.ninv[log_n], D.ninv_s[log_n], D.pinv_neg, 0, 0};
+        return K{D.p, 2 * D.p, (const FHE_CONST uint2 *)D.tw, (const FHE_CONST uint2 *)D.twi, D.ninv[log_n], D.ninv_s[log_n], D.pinv_neg, 0, 0};
     }
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
-        const FHE_GLOBAL uint2 *p = (INV ? k.twi : k.tw) + idx;
+        const FHE_CONST uint2 *p = (INV ? k.twi : k.tw) + idx;
         TwRaw r;
         r.x = p->x; r.y = p->y;
         return r;
