@@ -9,6 +9,7 @@
 // over util/src/ring/fft/zq.rs:14-19), d+2 instead of 6d per key switch (rlwe.rs:177-186).  All sums are
 // exact mod q, so the coefficient-domain outputs are bit-identical to the reference's.
 #pragma once
+#include <type_traits>
 #include "ntt_kernels.hpp"
 
 namespace fhe {
@@ -181,7 +182,10 @@ struct WaveRing {
     using C = NttCfg<LOG_N, LOG_E, 1>;  // T = TEAM
     static constexpr int R0 = C::R0;
     static constexpr int PN = C::PN;
-    static constexpr size_t LDS_BYTES = size_t(PN) * 8 * TEAMS;
+    // N = 1024 at 4 coefficients per lane: the FHEW kernels park the accumulator's b half in LDS across the gadget loop (one team per
+    // block: N words behind the exchange image) and are compiled for FOUR waves per SIMD -- see wave_gadget_product
+    static constexpr bool PARK = LOG_E_ == 2 && LOG_N_ == 10;
+    static constexpr size_t LDS_BYTES = size_t(PN + (PARK ? N : 0)) * 8 * TEAMS;
     static constexpr int TORUS_LDS_WORDS = PN + 2 * N;  // torus kernels: exchange image + parking area for one residue pair
     static constexpr size_t TORUS_LDS_BYTES = size_t(TORUS_LDS_WORDS) * 8 * TEAMS;
 #ifndef FHE_TEAM_OCC
@@ -196,6 +200,11 @@ struct WaveRing {
     static __device__ __forceinline__ int lane() { return threadIdx.x & (TEAM - 1); }  // thread within its team
     static __device__ __forceinline__ int team() { return threadIdx.x >> LOG_T; }      // team within the block
 };
+
+// launch bound of the two FHEW kernels: four waves per SIMD where the parked form fits them without a spill (the two-operand
+// policies; the Shoup products' temporaries do not: 10 registers spilled), W::MIN_WAVES otherwise (and in the torus kernels)
+template <class A, class W>
+constexpr int fhew_min_waves() { return (W::PARK && !std::is_same<A, ArithShoup>::value) ? 4 : W::MIN_WAVES; }
 
 // polynomial index held by register k of `lane` in the coefficient (first-pass) layout
 template <class W>
@@ -266,13 +275,25 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W
 #pragma unroll
     for (int e = 0; e < E; ++e) { ma[e] = mb[e] = A::mac_zero(); st[e] = decomp_init(ca[e], P); }
     const int total = both ? 2 * P.d : P.d;
+    // W::PARK (N = 1024, 4 coefficients per lane): four ciphertexts per CU need 128 registers.  Of the 148 the kernel took, 33 were
+    // loop-invariant: the b half of the accumulator (needed again only at limb d and at the end: parked in LDS) and exchange
+    // addresses of BOTH transform directions hoisted out of the limb loop.  Recomputing all of them per limb fits 128 registers but
+    // costs more instructions than the fourth ciphertext brings (59 k against 66 k blind rotations/s at batch 1024); recomputing
+    // only the inverse's (two inverse transforms per gadget product against 2d forward ones: the lane index is made opaque in front
+    // of them) fits 128 registers with no spill: 72.5 k -> 75.4 k at batch 4096, 58.5 k -> 64.5 k at 1024.
+    constexpr bool PARK = W::PARK;
+    u64 *park = lds + W::PN;
+    if constexpr (PARK) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) park[e * W::TEAM + lane] = cb[e];
+    }
     KeyRow<W> kr;
     load_row<W>(kr, rows, lane);
 #pragma unroll 1
     for (int j = 0; j < total; ++j) {
         if (both && j == P.d) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) st[e] = decomp_init(cb[e], P);
+            for (int e = 0; e < E; ++e) st[e] = decomp_init(PARK ? park[e * W::TEAM + lane] : cb[e], P);
         }
         u64 x[E];
 #pragma unroll
@@ -286,7 +307,9 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W
     // two inverse transforms through ONE instance: transform sa, swap, transform again
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
-        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
+        int ln = lane;
+        if constexpr (PARK) asm volatile("" : "+v"(ln));
+        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, ln, nullptr, lds, true, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) { const u64 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
     }
@@ -294,7 +317,7 @@ __device__ __forceinline__ void wave_gadget_product(u64 (&ca)[W::E], u64 (&cb)[W
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         ca[e] = sa[e];
-        cb[e] = both ? sb[e] : csub(sb[e] + cb[e], K.B.q);
+        cb[e] = both ? sb[e] : csub(sb[e] + (PARK ? park[e * W::TEAM + lane] : cb[e]), K.B.q);
     }
 }
 
@@ -337,7 +360,7 @@ struct FhewKey {      // device view of a prepared gadget key set
 //   both = 1: RLWE x RGSW external product; both = 0: RLWE key switch, preceded by X -> X^t2n when t2n != 1
 //   (scheme/fhew/src/rlwe.rs:188-191 `Rlwe::automorphism`)
 template <class A, class W>
-__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void gadget_product_kernel(
+__global__ __launch_bounds__(W::THREADS, (fhew_min_waves<A, W>())) void gadget_product_kernel(
     u64 *__restrict__ ct_a, u64 *__restrict__ ct_b, unsigned batch, FhewKey key, unsigned index, unsigned both, unsigned t2n,
     RingConsts K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -469,7 +492,7 @@ struct BlindRotateParams {
 };
 
 template <class A, class W>
-__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
+__global__ __launch_bounds__(W::THREADS, (fhew_min_waves<A, W>())) void blind_rotate_kernel(BlindRotateParams BR, u64 *__restrict__ out_a,
                                                                                   u64 *__restrict__ out_b, unsigned batch, RingConsts K) {
     constexpr int E = W::E, N = W::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
