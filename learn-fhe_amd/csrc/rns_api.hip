@@ -22,11 +22,14 @@ struct fhe_rns_ctx {
     void *d_blob = nullptr;            // all conversion tables
     fhe::BaseConv q2p{}, p2q{};
     fhe::RescaleConsts resc{};
-    fhe::RescaleConsts resc_last{};
-    bool ds = false;                   // every modulus is a 60-bit pseudo-Mersenne prime: conversions on the two-operand products    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
+    fhe::RescaleConsts resc_last{};    // `rescale()` = rescale_k(1) of a polynomial over qs: drops q_{L-1} (L >= 2)
     int max_log_n = 0;                 // largest ring degree every prime supports
     int all_pm = -1;                   // common pseudo-Mersenne bit length of all primes, 0 if none
-    fhe::EdgeConsts edge{};            // the transforms' outermost layer at N = 2^15 (rns_kernels.hpp), present when `ds`
+    // every modulus a pseudo-Mersenne prime of ONE bit length: the conversions run as unreduced dot products (rns_kernels.hpp)
+    bool pm = false;
+    fhe::pd::Uni uni{};
+    fhe::PmSrc s_q2p{}, s_p2q{}, s_p2q_sum{}, s_p2q_diff{}, s_last{};
+    fhe::PmRows r_q2p{}, r_q2p_w{}, r_resc{}, r_resc_edge{}, r_last{};
 };
 
 struct fhe_ckks_key {
@@ -61,14 +64,7 @@ struct BlobBuilder {
     }
 };
 
-struct ConvOffsets { size_t a_mod, ahat_inv, ahat_inv_s, frac, b_mod, c, c_s, ua, inv_ds, c_ds, a_c, b_c; int la, lb; };
-
-// {a0, a1, b0, b1} of ArithDS<60> as two blob words; w < q < 2^60
-void put_ds(std::vector<uint64_t> &out, uint64_t w, uint64_t q) {
-    const uint4 d = fhe::ArithDS<60>::split(w, q);
-    out.push_back((uint64_t)d.x | ((uint64_t)d.y << 32));
-    out.push_back((uint64_t)d.z | ((uint64_t)d.w << 32));
-}
+struct ConvOffsets { size_t a_mod, ahat_inv, ahat_inv_s, frac, b_mod, c, c_s, ua; int la, lb; };
 
 ConvOffsets build_conv(BlobBuilder &bb, const std::vector<uint64_t> &A, const std::vector<uint64_t> &B) {
     const int la = (int)A.size(), lb = (int)B.size();
@@ -91,19 +87,6 @@ ConvOffsets build_conv(BlobBuilder &bb, const std::vector<uint64_t> &A, const st
     o.la = la; o.lb = lb;
     o.a_mod = bb.put(A); o.ahat_inv = bb.put(inv); o.ahat_inv_s = bb.put(inv_s); o.frac = bb.put_f64(frac);
     o.b_mod = bb.put(B); o.c = bb.put(c); o.c_s = bb.put(c_s); o.ua = bb.put(ua);
-    // two-operand forms (read only when the context's `ds` flag is set; harmless otherwise)
-    std::vector<uint64_t> inv_ds, c_ds, a_c, b_c;
-    for (int i = 0; i < la; ++i) put_ds(inv_ds, inv[i], A[i]);
-    for (int j = 0; j < lb; ++j)
-        for (int i = 0; i < la; ++i) put_ds(c_ds, c[size_t(j) * la + i], B[j]);
-    // 32-bit c values packed two per word
-    auto pack_c = [](const std::vector<uint64_t> &M) {
-        std::vector<uint64_t> w((M.size() + 1) / 2, 0);
-        for (size_t i = 0; i < M.size(); ++i) w[i / 2] |= (uint64_t)(uint32_t)((uint64_t(1) << 60) - M[i]) << (32 * (i & 1));
-        return w;
-    };
-    if (bb.words.size() & 1) bb.words.push_back(0);  // 16-byte alignment of the uint4 tables
-    o.inv_ds = bb.put(inv_ds); o.c_ds = bb.put(c_ds); o.a_c = bb.put(pack_c(A)); o.b_c = bb.put(pack_c(B));
     return o;
 }
 
@@ -113,11 +96,67 @@ fhe::BaseConv conv_view(const ConvOffsets &o, const uint64_t *base) {
     C.a_mod = (const u64 *)base + o.a_mod; C.ahat_inv = (const u64 *)base + o.ahat_inv; C.ahat_inv_s = (const u64 *)base + o.ahat_inv_s;
     C.frac = (const double *)(base + o.frac);
     C.b_mod = (const u64 *)base + o.b_mod; C.c = (const u64 *)base + o.c; C.c_s = (const u64 *)base + o.c_s; C.ua = (const u64 *)base + o.ua;
-    C.ahat_inv_ds = (const uint4 *)(base + o.inv_ds); C.c_ds = (const uint4 *)(base + o.c_ds);
-    C.a_c = (const unsigned *)(base + o.a_c); C.b_c = (const unsigned *)(base + o.b_c);
-    C.pw = 1u << 29;
     return C;
 }
+
+// ---- tables of the pseudo-Mersenne route (rns_kernels.hpp: PmSrc / PmRows; pm_dot.hpp) -----------------------------------------
+// everything is laid into the same blob; 32-bit tables two per word, 16-byte tables on 16-byte boundaries
+size_t put_u32(BlobBuilder &bb, const std::vector<uint32_t> &v) {
+    std::vector<uint64_t> w((v.size() + 1) / 2, 0);
+    for (size_t i = 0; i < v.size(); ++i) w[i / 2] |= (uint64_t)v[i] << (32 * (i & 1));
+    return bb.put(w);
+}
+// {a0, a1, b0, b1} of the two-operand form (arith.hpp ArithDS) for a B-bit modulus q
+void push_ds(std::vector<uint32_t> &out, uint64_t w, uint64_t q, int B) {
+    const uint64_t w1 = (uint64_t)((((fhe::u128)w) << 32) % q), lo = (uint64_t(1) << (B - 31)) - 1;
+    out.push_back((uint32_t)(w & lo)); out.push_back((uint32_t)(w >> (B - 31)));
+    out.push_back((uint32_t)(w1 & lo)); out.push_back((uint32_t)(w1 >> (B - 31)));
+}
+// source-side records (rns_kernels.hpp PmSrc): vs_i = (v_i mult_i + hk_i) mod a_i; w_i = tw[1] of a_i (or 0)
+size_t build_src(BlobBuilder &bb, const std::vector<uint64_t> &A, const std::vector<uint64_t> &mult, const std::vector<uint64_t> &hk,
+                 const std::vector<uint64_t> &w, int B) {
+    std::vector<uint32_t> rec;
+    for (int i = 0; i < (int)A.size(); ++i) {
+        const double frac = 1.0 / (double)A[i];  // rns.rs:294
+        uint64_t fbits;
+        std::memcpy(&fbits, &frac, 8);
+        rec.push_back((uint32_t)A[i]); rec.push_back((uint32_t)(A[i] >> 32));
+        rec.push_back((uint32_t)((uint64_t(1) << B) - A[i])); rec.push_back(0);
+        push_ds(rec, mult[i], A[i], B);
+        rec.push_back((uint32_t)hk[i]); rec.push_back((uint32_t)(hk[i] >> 32));
+        rec.push_back((uint32_t)fbits); rec.push_back((uint32_t)(fbits >> 32));
+        push_ds(rec, w[i], A[i], B);
+    }
+    if (bb.words.size() & 7) bb.words.resize((bb.words.size() + 7) & ~size_t(7), 0);  // 64-byte records on 64-byte boundaries
+    return put_u32(bb, rec);
+}
+fhe::PmSrc src_view(size_t off, int la, const uint64_t *base) { return fhe::PmSrc{la, (const unsigned *)(base + off)}; }
+
+struct RowOffsets { size_t tab; int stride; };
+// rows over the moduli Bm (rns_kernels.hpp PmRows): M[j][i] (la columns), the multiplier U[j] of u, the multipliers X[j] / X2[j] of the
+// limb's own value (pair sum / pair difference), the constant term KC[j]
+RowOffsets build_rows(BlobBuilder &bb, const std::vector<uint64_t> &Bm, int la, const std::vector<uint64_t> &M, const std::vector<uint64_t> &Uv,
+                      const std::vector<uint64_t> &X, const std::vector<uint64_t> &X2, const std::vector<uint64_t> &KC, int B) {
+    const int rows = (int)Bm.size(), stride = (la + 7) / 8 * 8, row_dw = 3 * stride + fhe::PM_ROW_TAIL;
+    const uint32_t m30 = (1u << 30) - 1;
+    std::vector<uint32_t> tab(size_t(rows) * row_dw, 0);
+    for (int j = 0; j < rows; ++j) {
+        uint32_t *t = tab.data() + size_t(j) * row_dw;
+        for (int i = 0; i < la; ++i) {
+            const uint64_t m = M[size_t(j) * la + i];
+            t[i] = (uint32_t)m & m30; t[stride + i] = (uint32_t)(m >> 30); t[2 * stride + i] = t[i] + t[stride + i];
+        }
+        uint32_t *k = t + 3 * stride;
+        const uint64_t c = (uint64_t(1) << B) - Bm[j];
+        k[0] = (uint32_t)Uv[j] & m30; k[1] = (uint32_t)(Uv[j] >> 30);
+        k[2] = (uint32_t)X[j] & m30; k[3] = (uint32_t)(X[j] >> 30); k[4] = (uint32_t)X2[j] & m30; k[5] = (uint32_t)(X2[j] >> 30);
+        k[6] = (uint32_t)c; k[7] = (uint32_t)(c << (60 - B));
+        k[8] = (uint32_t)Bm[j]; k[9] = (uint32_t)(Bm[j] >> 32); k[10] = (uint32_t)KC[j]; k[11] = (uint32_t)(KC[j] >> 32);
+    }
+    if (bb.words.size() & 7) bb.words.resize((bb.words.size() + 7) & ~size_t(7), 0);
+    return RowOffsets{put_u32(bb, tab), stride};
+}
+fhe::PmRows rows_view(const RowOffsets &o, const uint64_t *base) { return fhe::PmRows{o.stride, (const unsigned *)(base + o.tab)}; }
 
 inline unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
@@ -180,17 +219,6 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     }
     for (int j = 0; j < K; ++j) half_p[j] = half_of_p(ps[j]);
     const size_t o_hq = bb.put(half_q), o_hp = bb.put(half_p), o_pi = bb.put(pinv), o_pis = bb.put(pinv_s), o_mu = bb.put(red_mu);
-    std::vector<uint64_t> pinv_ds;
-    for (int i = 0; i < L; ++i) put_ds(pinv_ds, pinv[i], qs[i]);
-    if (bb.words.size() & 1) bb.words.push_back(0);
-    const size_t o_pids = bb.put(pinv_ds);
-    // tw[1], n^-1 and n^-1 twi[1] of every modulus at n = 2^15 (the edge kernels; read only when `ds`)
-    std::vector<uint64_t> e_w, e_n, e_nw;
-    for (int i = 0; i < L + K; ++i) {
-        const fhe_ctx *c = r->mods[i];
-        put_ds(e_w, c->tw.size() > 1 ? c->tw[1] : 0, c->q); put_ds(e_n, c->ninv[15], c->q); put_ds(e_nw, c->ninv_w[15], c->q);
-    }
-    const size_t o_ew = bb.put(e_w), o_en = bb.put(e_n), o_enw = bb.put(e_nw);
     // rns.rs:99-101 `rescale()`: the same formulas with P = the last q-limb (rns.rs:104-111, the K == 1 branch)
     std::vector<uint64_t> lhalf_q(L), lhalf_p(1), lpinv(L), lpinv_s(L);
     if (L >= 2) {
@@ -203,10 +231,80 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
         }
     }
     const size_t o_lhq = bb.put(lhalf_q), o_lhp = bb.put(lhalf_p), o_lpi = bb.put(lpinv), o_lpis = bb.put(lpinv_s);
-    std::vector<uint64_t> lpinv_ds;
-    for (int i = 0; i < L; ++i) put_ds(lpinv_ds, lpinv[i], qs[i]);
-    if (bb.words.size() & 1) bb.words.push_back(0);
-    const size_t o_lpids = bb.put(lpinv_ds);
+    // ---- the pseudo-Mersenne route (rns_kernels.hpp): every linear step folded into the constants of unreduced dot products ----
+    r->pm = r->all_pm >= 34 && r->all_pm <= 60;
+    size_t so_q2p = 0, so_p2q = 0, so_sum = 0, so_diff = 0, so_last = 0;
+    RowOffsets ro_q2p{}, ro_q2p_w{}, ro_resc{}, ro_edge{}, ro_last{};
+    if (r->pm) {
+        const int B = r->all_pm;
+        const std::vector<uint64_t> &Q = r->qs, &P = r->ps;
+        auto hat_inv = [&](const std::vector<uint64_t> &A) {  // (A / a_i)^-1 mod a_i (rns.rs:290-293)
+            std::vector<uint64_t> v(A.size());
+            for (int i = 0; i < (int)A.size(); ++i) v[i] = fhe::invmod(prod_mod(A, i, A[i]), A[i]);
+            return v;
+        };
+        // tw[1], n^-1 and n^-1 twi[1] at n = 2^15 of modulus i of qs ++ ps (the edge kernels; zero where the modulus has no such root)
+        auto tw1 = [&](int i) { const fhe_ctx *c = r->mods[i]; return c->tw.size() > 1 ? c->tw[1] : 0; };
+        auto nv = [&](int i) { return r->mods[i]->ninv[15]; };
+        auto nw = [&](int i) { return r->mods[i]->ninv_w[15]; };
+        // extend Q -> P: out_j = sum_i (Q/q_i mod p_j) vs_i + u (p_j - Q mod p_j)
+        {
+            const std::vector<uint64_t> inv = hat_inv(Q), zero(L, 0);
+            std::vector<uint64_t> fw(L);
+            for (int i = 0; i < L; ++i) fw[i] = tw1(i);
+            so_q2p = build_src(bb, Q, inv, zero, fw, B);
+            std::vector<uint64_t> M(size_t(K) * L), MW(size_t(K) * L), Uv(K), UW(K), z(K, 0);
+            for (int j = 0; j < K; ++j) {
+                const uint64_t b = P[j], w = tw1(L + j);
+                for (int i = 0; i < L; ++i) {
+                    M[size_t(j) * L + i] = prod_mod(Q, i, b);
+                    MW[size_t(j) * L + i] = mulmod(M[size_t(j) * L + i], w, b);
+                }
+                Uv[j] = (b - prod_mod(Q, -1, b)) % b;
+                UW[j] = mulmod(Uv[j], w, b);
+            }
+            ro_q2p = build_rows(bb, P, L, M, Uv, z, z, z, B);
+            ro_q2p_w = build_rows(bb, P, L, MW, UW, z, z, z, B);
+        }
+        // rescale_k(K): vs_j = (v_j + half_j) inv_j; out_l = sum_j (-(P/p_j) P^-1) vs_j + u + x P^-1 + half_l P^-1  (mod q_l)
+        {
+            const std::vector<uint64_t> inv = hat_inv(P);
+            std::vector<uint64_t> hk(K), inv_sum(K), inv_diff(K);
+            for (int j = 0; j < K; ++j) {
+                hk[j] = mulmod(half_p[j], inv[j], P[j]);
+                inv_sum[j] = mulmod(nv(L + j), inv[j], P[j]);
+                inv_diff[j] = mulmod(nw(L + j), inv[j], P[j]);
+            }
+            const std::vector<uint64_t> zk(K, 0);
+            so_p2q = build_src(bb, P, inv, hk, zk, B);
+            so_sum = build_src(bb, P, inv_sum, hk, zk, B);
+            so_diff = build_src(bb, P, inv_diff, hk, zk, B);
+            std::vector<uint64_t> M(size_t(L) * K), one(L, 1), X(L), XS(L), XD(L), KC(L), z(L, 0);
+            for (int l = 0; l < L; ++l) {
+                const uint64_t q = Q[l];
+                for (int j = 0; j < K; ++j) M[size_t(l) * K + j] = mulmod((q - prod_mod(P, j, q)) % q, pinv[l], q);
+                X[l] = pinv[l];
+                XS[l] = mulmod(nv(l), pinv[l], q);
+                XD[l] = mulmod(nw(l), pinv[l], q);
+                KC[l] = mulmod(half_q[l], pinv[l], q);
+            }
+            ro_resc = build_rows(bb, Q, K, M, one, X, z, KC, B);
+            ro_edge = build_rows(bb, Q, K, M, one, XS, XD, KC, B);
+        }
+        // rescale(): P = the last q-limb, K == 1 (no correction term)
+        if (L >= 2) {
+            const std::vector<uint64_t> last(1, Q[L - 1]), one1(1, 1), hk1(1, Q[L - 1] >> 1);
+            so_last = build_src(bb, last, one1, hk1, std::vector<uint64_t>(1, 0), B);
+            const std::vector<uint64_t> Ql(Q.begin(), Q.end() - 1);
+            std::vector<uint64_t> M(L - 1), X(L - 1), KC(L - 1), z(L - 1, 0);
+            for (int l = 0; l + 1 < L; ++l) {
+                M[l] = (Ql[l] - lpinv[l]) % Ql[l];
+                X[l] = lpinv[l];
+                KC[l] = mulmod(lhalf_q[l], lpinv[l], Ql[l]);
+            }
+            ro_last = build_rows(bb, Ql, 1, M, z, X, z, KC, B);
+        }
+    }
     std::vector<fhe::ModDesc> descs(L + K);
     std::vector<fhe::Barrett> bar(L + K);
     for (int i = 0; i < L + K; ++i) { descs[i] = r->mods[i]->h_desc; bar[i] = r->mods[i]->barrett; }
@@ -225,16 +323,20 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     r->resc.half_q = (const u64 *)base + o_hq; r->resc.half_p = (const u64 *)base + o_hp;
     r->resc.pinv = (const u64 *)base + o_pi; r->resc.pinv_s = (const u64 *)base + o_pis;
     r->resc.red_mu = (const u64 *)base + o_mu;
-    r->resc.pinv_ds = (const uint4 *)(base + o_pids);
     r->resc.p2q = r->p2q;
-    r->ds = r->all_pm == 60;
-    r->edge = fhe::EdgeConsts{(const uint4 *)(base + o_ew), (const uint4 *)(base + o_en), (const uint4 *)(base + o_enw)};
     r->resc_last = r->resc;  // p2q unused when K == 1
     r->resc_last.L = L - 1; r->resc_last.K = 1;
     r->resc_last.p_mod = r->q2p.a_mod + (L - 1);
     r->resc_last.half_q = (const u64 *)base + o_lhq; r->resc_last.half_p = (const u64 *)base + o_lhp;
     r->resc_last.pinv = (const u64 *)base + o_lpi; r->resc_last.pinv_s = (const u64 *)base + o_lpis;
-    r->resc_last.pinv_ds = (const uint4 *)(base + o_lpids);
+    if (r->pm) {
+        r->uni = fhe::pd::make_uni(r->all_pm);
+        r->s_q2p = src_view(so_q2p, L, base); r->s_p2q = src_view(so_p2q, K, base);
+        r->s_p2q_sum = src_view(so_sum, K, base); r->s_p2q_diff = src_view(so_diff, K, base);
+        r->r_q2p = rows_view(ro_q2p, base); r->r_q2p_w = rows_view(ro_q2p_w, base);
+        r->r_resc = rows_view(ro_resc, base); r->r_resc_edge = rows_view(ro_edge, base);
+        if (L >= 2) { r->s_last = src_view(so_last, 1, base); r->r_last = rows_view(ro_last, base); }
+    }
     *out = r;
     return FHE_OK;
 }
@@ -244,6 +346,7 @@ namespace {
 #define RNS_BOUND(la, CALL)                                              \
     do {                                                                 \
         if ((la) == 8) { CALL(8, true); } /* the BASELINE shape: no limb predicates at all */ \
+        else if ((la) == 1) { CALL(1, true); } /* `rescale()` and K = 1 */ \
         else if ((la) <= 4) { CALL(4, false); }                          \
         else if ((la) <= 8) { CALL(8, false); }                          \
         else if ((la) <= 16) { CALL(16, false); }                        \
@@ -257,31 +360,50 @@ struct PointwiseGrid {
         g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
     }
 };
-void launch_extend(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, bool ds, hipStream_t st,
+// extend_bases(qs -> ps): in [batch][L][n] -> out [batch][K][n]; `copy` (optional) receives the source limbs
+void launch_extend(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st,
                    u64 *copy = nullptr, size_t copy_bs = 0) {
-#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs); \
-                        else hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs); } while (0)
-    RNS_BOUND(C.la, CALL);
+    const dim3 grid(grid_for(n * batch));
+    if (r->pm) {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, r->s_q2p, r->r_q2p, r->K, r->uni, copy, copy_bs)
+        RNS_BOUND(r->L, CALL);
+#undef CALL
+    } else {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, r->q2p, copy, copy_bs)
+        RNS_BOUND(r->L, CALL);
+#undef CALL
+    }
+}
+// rescale_k(K) (last = false: in [batch][L+K][n] -> out [batch][L][n]) or rescale() (last = true: in [batch][L][n] -> [batch][L-1][n])
+void launch_rescale(const fhe_rns_ctx *r, bool last, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
+                    size_t batch, hipStream_t st) {
+    const dim3 grid(grid_for(n * batch));
+    const int k = last ? 1 : r->K, L = last ? r->L - 1 : r->L;
+    if (r->pm) {
+        const fhe::PmSrc &S = last ? r->s_last : r->s_p2q;
+        const fhe::PmRows &R = last ? r->r_last : r->r_resc;
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, L, S, R, r->uni)
+        RNS_BOUND(k, CALL);
+#undef CALL
+    } else {
+        const fhe::RescaleConsts &R = last ? r->resc_last : r->resc;
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
+        RNS_BOUND(k, CALL);
+#undef CALL
+    }
+}
+// the same two steps with the outermost transform layer of a 2^15 ring in them (rns_kernels.hpp); pseudo-Mersenne bases only
+void launch_extend_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st) {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_edge_pm_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, \
+                                      r->s_q2p, r->r_q2p, r->r_q2p_w, r->K, r->uni)
+    RNS_BOUND(r->L, CALL);
 #undef CALL
 }
-void launch_rescale(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
-                    const fhe::RescaleConsts &R, bool ds, hipStream_t st) {
-#define CALL(M, F) do { if (ds) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F, true>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R); \
-                        else hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F, false>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R); } while (0)
-    RNS_BOUND(R.K, CALL);
-#undef CALL
-}
-// the same two kernels with the outermost transform layer of a 2^15 ring in them (rns_kernels.hpp); two-operand products only
-void launch_extend_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, const fhe::BaseConv &C, const fhe::EdgeConsts &E,
-                        hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_edge_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, E.fwd_w)
-    RNS_BOUND(C.la, CALL);
-#undef CALL
-}
-void launch_rescale_edge(const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n, size_t batch,
-                         const fhe::RescaleConsts &R, const fhe::EdgeConsts &E, hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_kernel<M, F>), dim3(grid_for(n * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R, E)
-    RNS_BOUND(R.K, CALL);
+void launch_rescale_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
+                         size_t batch, hipStream_t st) {
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_pm_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, \
+                                      add_bs, n, batch, r->L, r->s_p2q_sum, r->s_p2q_diff, r->r_resc_edge, r->uni)
+    RNS_BOUND(r->K, CALL);
 #undef CALL
 }
 // FHE_RING_NO_EDGE=1: the key switch keeps whole 2^15 transforms (A/B runs and the test that both routes agree bit for bit)
@@ -300,7 +422,7 @@ int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out
     if (!guard.ok) return FHE_ERR_HIP;
     Mirror mi(in, n * batch * r->L, mem, true, st), mo(out, n * batch * r->K, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_extend(mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, r->q2p, r->ds, st);
+    launch_extend(r, mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -315,7 +437,7 @@ int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, s
     const size_t lk = size_t(r->L + r->K);
     Mirror mi(in, n * batch * lk, mem, true, st), mo(out, n * batch * r->L, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, r->resc, r->ds, st);
+    launch_rescale(r, false, mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -418,10 +540,10 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
     u64 *ws = wsp.as<u64>();
     u64 *ext = ws, *pb = ws + blk;
     int rc = FHE_OK;
-    if (log_n == 15 && r->ds && r->L <= 8 && r->K <= 8 && edge_enabled()) {  // (wider bases: two limb vectors per thread would spill)
+    if (log_n == 15 && r->pm && r->L <= 8 && r->K <= 8 && edge_enabled()) {  // (wider bases: two limb vectors per thread would spill)
         // N = 2^15 (cfg4): layer 0 of the forward transforms runs inside the extend kernel, layer 0 of the inverse ones (and n^-1)
         // inside the rescales; the transform launches are 2^14 sub-transforms, two workgroups per CU (rns_kernels.hpp)
-        launch_extend_edge(a_in, L * n, ext, lk * n, n, batch, r->q2p, r->edge, st);
+        launch_extend_edge(r, a_in, L * n, ext, lk * n, n, batch, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
         if (rc == FHE_OK) rc = fhe::ntt_fwd_inner15(r->d_descs, (unsigned)lk, ext, batch * lk, st, r->all_pm);
         if (rc == FHE_OK) {
@@ -431,14 +553,14 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
             rc = fhe::ntt_inv_inner15(r->d_descs, (unsigned)lk, pb, 2 * batch * lk, st, r->all_pm, io);
         }
         if (rc == FHE_OK) {
-            launch_rescale_edge(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, r->edge, st);
-            launch_rescale_edge(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, r->edge, st);
+            launch_rescale_edge(r, pb, lk * n, out_b, L * n, add_b, L * n, n, batch, st);
+            launch_rescale_edge(r, pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, st);
             if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
         }
         return rc;
     }
     // ext[:, :L] = ct_a; ext[:, L:] = extend_bases(ct_a, ps): one kernel, the q-limbs written back out of the registers it read them into
-    launch_extend(a_in, L * n, ext + L * n, lk * n, n, batch, r->q2p, r->ds, st, ext, lk * n);
+    launch_extend(r, a_in, L * n, ext + L * n, lk * n, n, batch, st, ext, lk * n);
     if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK && n > 1) rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)lk, ext, log_n, batch * lk, st, r->all_pm);
     // ksk.b * a~ and ksk.a * a~ (ring/rns.rs:148-158) ride on the load of ONE inverse launch over the 2 * batch * lk output
@@ -454,8 +576,8 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) {
-        launch_rescale(pb, lk * n, out_b, L * n, add_b, L * n, n, batch, r->resc, r->ds, st);
-        launch_rescale(pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, r->resc, r->ds, st);
+        launch_rescale(r, false, pb, lk * n, out_b, L * n, add_b, L * n, n, batch, st);
+        launch_rescale(r, false, pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     return rc;
@@ -492,7 +614,7 @@ int fhe_rns_rescale(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, siz
     const size_t L = r->L;
     Mirror mi(in, n * batch * L, mem, true, st), mo(out, n * batch * (L - 1), mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
+    launch_rescale(r, true, mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -593,8 +715,8 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
     // (d0, d1) + relinearize(d2) (ckks.rs:262, 265-272): the key switch adds d0 and d1 as it rescales; its outputs reuse e
     if (rc == FHE_OK) rc = key_switch_dev(r, rlk, d + 2 * words, d, d + words, e, e + words, batch, st);
     if (rc == FHE_OK) {
-        launch_rescale(e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
-        launch_rescale(e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, r->resc_last, r->ds, st);
+        launch_rescale(r, true, e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, st);
+        launch_rescale(r, true, e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) rc = mob.sync_out(st);
