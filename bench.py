@@ -29,7 +29,8 @@ LOG_N = 14
 BATCH = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 ALGO_BYTES_PER_NTT = 16 * (1 << LOG_N)  # 8N read + 8N write
-FWD_KERNEL = "ntt14w_fwd_kernel<ArithDS<60>, false> (forward transform)"
+FWD_KERNEL = "ntt14w_fwd_kernel<ArithDS<60>, false, 3> (forward transform)"
+INV_KERNEL = "ntt14w_inv_kernel<ArithDS<60>, false, false, 3> (inverse transform)"
 
 
 def roof(units_per_sec, bytes_per_unit, kernel, note=None):
@@ -81,7 +82,7 @@ def _timeit(torch, fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def ntt_mul_bench(torch, F, dev, local_rank, batch, reps=20):
+def ntt_mul_bench(torch, F, dev, local_rank, batch, reps=20, verify=True):
     """`Rq * Rq` (util/src/ring/fft/zq.rs:14-19) on cfg2's ring: 3 launches, 24 N algorithmic bytes (read a, b; write c)."""
     n = 1 << LOG_N
     ctx = F.NttContext(Q, device=local_rank)
@@ -89,9 +90,18 @@ def ntt_mul_bench(torch, F, dev, local_rank, batch, reps=20):
     gen.manual_seed(12)
     a = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
     b = torch.randint(0, Q, (batch, n), dtype=torch.int64, device=dev, generator=gen)
+    a0 = a.clone()
     dt = _timeit(torch, lambda: ctx.mul_(a, b, n), reps)
     out = {"workload": "ring product a *= b, N=2^14, q=%d, batch=%d" % (Q, batch), "products_per_sec": batch / dt,
            "hbm_traffic_bytes_per_product_by_construction": 40 * n}
+    if verify:  # one launch of the timed shape on the untouched operands, first and last product against the CPU oracle
+        import numpy as np
+        from oracle import cref
+        u = lambda t, i: t[i].cpu().numpy().view(np.uint64)  # noqa: E731
+        left = {i: u(a0, i).copy() for i in (0, batch - 1)}
+        ctx.mul_(a0, b, n)
+        out["verified"] = bool(all(np.array_equal(u(a0, i), cref.ntt_mul(Q, left[i], u(b, i), n)) for i in (0, batch - 1)))
+        out["verification"] = "ring product at batch %d: products 0 and %d bit-equal to the CPU oracle" % (batch, batch - 1)
     out["roofline"] = roof(batch / dt, 24 * n, "ntt14w_fwd_kernel (right operand, out of place) + ntt14w_mul_kernel (forward of the left operand, pointwise product, inverse: one workgroup, one load and one store)")
     return out
 
@@ -103,14 +113,15 @@ def fhew_setup(torch, F, dev, local_rank):
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
     rnd = lambda *shape, m=q: torch.randint(0, m, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
-    brk = F.GadgetKey(ctx, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n, rgsw=True)
-    ak = F.GadgetKey(ctx, log_b, d, rnd(w + 1, d, n), rnd(w + 1, d, n), n, rgsw=False)
+    raw = [rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), rnd(w + 1, d, n), rnd(w + 1, d, n)]  # brk a | b rows, ak a | b rows
+    brk = F.GadgetKey(ctx, log_b, d, raw[0], raw[1], n, rgsw=True)
+    ak = F.GadgetKey(ctx, log_b, d, raw[2], raw[3], n, rgsw=False)
     bk = F.BootstrapKey(ctx, brk, ak, F.ak_t(n, w), w)
-    return dict(q=q, n=n, log_b=log_b, d=d, w=w, n_lwe=n_lwe, q_ks=q_ks, kb=kb, kd=kd, ctx=ctx, gen=gen, rnd=rnd, brk=brk, ak=ak, bk=bk,
+    return dict(q=q, n=n, log_b=log_b, d=d, w=w, n_lwe=n_lwe, q_ks=q_ks, kb=kb, kd=kd, ctx=ctx, gen=gen, rnd=rnd, brk=brk, ak=ak, bk=bk, raw=raw,
                 ksk_a=rnd(kd * n, n_lwe, m=q_ks), ksk_b=rnd(kd * n, m=q_ks), f=rnd(n))
 
 
-def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
+def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3, verify=True):
     """Secondary metric of BASELINE.json ("+ FHEW gate-bootstraps/sec"): BASELINE config 3 -- the full LMKCDEY blind
     rotation (bootstrapping.rs:158-209: ~100 external products + ~150 automorphism key switches per ciphertext) at
     N = 2^10, q = 18014398509404161, base 2^6, d = 9, LWE n = 100, w = 10, uniform-random keys, device resident; and the
@@ -126,6 +137,20 @@ def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
         lwe_b = torch.randint(0, 2 * n, (batch,), dtype=torch.int64, device=dev, generator=gen)
         dt = _timeit(torch, lambda: bk.blind_rotate(lwe_a, lwe_b, S["f"]), reps)
         out["blind_rotations_per_sec_batch%d" % batch] = batch / dt
+        if verify and batch == max(batches):  # the largest timed launch: first and last ciphertext against the CPU oracle
+            import numpy as np
+            from oracle import cref
+            u = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+            oa, ob = bk.blind_rotate(lwe_a, lwe_b, S["f"])[:2]
+            brk_h = np.stack([u(S["raw"][0]), u(S["raw"][1])], axis=1)  # [key][a|b][row][n] as the oracle takes it
+            ak_h = np.stack([u(S["raw"][2]), u(S["raw"][3])], axis=1)
+            ts = [int(t) for t in F.ak_t(n, S["w"])]
+            ok = True
+            for i in (0, batch - 1):
+                ea, eb = cref.blind_rotate(q, n, S["w"], S["log_b"], d, S["log_b"], d, brk_h, ak_h, ts, u(S["f"]), u(lwe_a[i]), int(lwe_b[i]))
+                ok = ok and np.array_equal(u(oa[i]), ea) and np.array_equal(u(ob[i]), eb)
+            out["verified"] = bool(ok)
+            out["verification"] = "blind rotation at batch %d: ciphertexts 0 and %d bit-equal to the CPU oracle" % (batch, batch - 1)
         if batch == 1024:
             # automorphism key switches per blind rotation: data dependent (bootstrapping.rs:172-231); counted on 64 ciphertexts of this batch
             _, _, sched = bk.blind_rotate(lwe_a[:64].contiguous(), lwe_b[:64].contiguous(), S["f"], want_schedule=True)
@@ -152,7 +177,7 @@ def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3):
     return out
 
 
-def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
+def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3, verify=True):
     """BASELINE config 4 on one GPU: CKKS key switch (scheme/ckks/src/ckks.rs:284-293) with CkksParam::new(15, 60, 8):
     N = 2^15, 8 + 8 sixty-bit primes (two_adic_primes(60, 16)), `batch` ciphertexts resident in HBM."""
     import ctypes as C
@@ -165,12 +190,27 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3):
     gen.manual_seed(4)
     limbs = lambda ms, *lead: torch.stack([torch.randint(0, m, (*lead, n), dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
                                            for m in ms], dim=len(lead)).contiguous()
-    key = F.CkksKey(rns, limbs(qs + ps), limbs(qs + ps), n)
+    kb_raw, ka_raw = limbs(qs + ps), limbs(qs + ps)
+    key = F.CkksKey(rns, kb_raw, ka_raw, n)
     out = {"workload": "cfg4: CKKS key switch N=2^15, 8+8 60-bit primes"}
     for b in (batch, 8 * batch):
         cb, ca = limbs(qs, b), limbs(qs, b)
-        dt = _timeit(torch, lambda: key.key_switch_(cb, ca), reps)
+        cb0, ca0 = cb.clone(), ca.clone()
+        dt = _timeit(torch, lambda: key.key_switch_(cb, ca), max(reps, 10 if b >= 64 else reps))
         out["key_switches_per_sec_batch%d" % b] = b / dt
+        if verify and b == 8 * batch:  # one launch sequence of the timed shape on the untouched inputs, first and last ciphertext against the CPU oracle
+            import numpy as np
+            from oracle import cref
+            u = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+            wb, wa = cb0.clone(), ca0.clone()
+            key.key_switch_(wb, wa)
+            ok = True
+            for i in (0, b - 1):
+                eb, ea = cref.ckks_key_switch(qs, ps, u(kb_raw), u(ka_raw), u(cb0[i]), u(ca0[i]))
+                ok = ok and np.array_equal(u(wb[i]), eb) and np.array_equal(u(wa[i]), ea)
+            out["verified"] = bool(ok)
+            out["verification"] = "key switch at batch %d: ciphertexts 0 and %d, all 2 x 8 output limbs bit-equal to the CPU oracle" % (b, b - 1)
+        del cb0, ca0
     # `Ckks::mul` (ckks.rs:250-263: tensor + relinearisation + rescale) on the same parameter set, 7 L transforms + one key switch
     b = 2 * batch
     c4 = [limbs(qs, b) for _ in range(4)]
@@ -190,12 +230,13 @@ def tfhe_setup(torch, F, dev, local_rank, batch):
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
     rnd = lambda *shape: torch.randint(-(1 << 63), (1 << 63) - 1, shape, dtype=torch.int64, device=dev, generator=gen)  # noqa: E731
-    key = F.TggswKey(t, log_b, d, rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), n)
+    raw = [rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n)]
+    key = F.TggswKey(t, log_b, d, raw[0], raw[1], n)
     return dict(n=n, n_lwe=n_lwe, log_b=log_b, d=d, ks_lb=ks_lb, ks_d=ks_d, t=t, key=key, ksa=rnd(n * ks_d, n_lwe), ksb=rnd(n * ks_d), v=rnd(n),
-                a_raw=rnd(batch, n_lwe), b_raw=rnd(batch))
+                a_raw=rnd(batch, n_lwe), b_raw=rnd(batch), raw=raw)
 
 
-def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
+def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=3, verify=True):
     """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
     bootstrapping.rs:78-104) at N = 2^10, k = 1, through the single-call gate fhe_tfhe_bootstrap: mod switch, n_lwe = 630 CMUXes
     (base 2^7, d = 3 -- the reference ships no N = 2^10 parameter set; these are the usual ones for that ring), sample extract,
@@ -205,6 +246,17 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
     dt = _timeit(torch, lambda: S["key"].bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"]), reps)
     out = {"workload": "cfg5 (one GPU's share): TFHE gate bootstrap N=2^10 k=1 n_lwe=630 (7,3) ks (4,5), batch=%d" % batch,
            "gate_bootstraps_per_sec": batch / dt}
+    if verify:  # the timed call's outputs: first and last ciphertext against the EXACT CPU oracle (wrapping schoolbook products)
+        import numpy as np
+        from oracle import cref
+        u = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+        ga, gb = S["key"].bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"])
+        pick = [0, batch - 1]
+        ea, eb = cref.tfhe_bootstrap(S["log_b"], S["d"], S["ks_lb"], S["ks_d"], u(S["raw"][0]), u(S["raw"][1]), u(S["ksa"]), u(S["ksb"]), u(S["v"]),
+                                     u(S["a_raw"])[pick], u(S["b_raw"])[pick], threads=max(1, min(os.cpu_count() or 1, 16)))
+        ha, hb = u(ga).reshape(batch, S["n_lwe"]), u(gb).reshape(batch)
+        out["verified"] = bool(all(np.array_equal(ha[i], ea[j]) and int(hb[i]) == int(eb[j]) for j, i in enumerate(pick)))
+        out["verification"] = "gate bootstrap at batch %d: ciphertexts 0 and %d bit-equal to the exact CPU oracle" % (batch, batch - 1)
     cmux_bytes = (4 * S["d"] + 4) * 8 * S["n"]  # as an RGSW external product: ct in + 2d rows x 2 + ct out
     out["roofline"] = roof(batch / dt, S["n_lwe"] * cmux_bytes, "torus30_blind_rotate_kernel<TorusRing30<10>> (630 CMUXes in one launch)",
                            "%d CMUXes x %d B per gate (TLWE key switch not counted); TGGSW rows are cache hits: bound by VALU issue" % (S["n_lwe"], cmux_bytes))
@@ -212,8 +264,8 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=1):
 
 
 def cpu_secondary_baselines():
-    """cfg3 / cfg4 / cfg5 units on host cores with the oracle's C restatement (kind "port"): one core each (the reference is
-    single-threaded), bounded samples."""
+    """cfg3 / cfg4 / cfg5 units on host cores with the oracle's C restatement (kind "port"): one core (the reference is
+    single-threaded: `single_thread_value`) and all cores of the box's share (one unit per thread: `value`), bounded samples."""
     import numpy as np
     from oracle import cref
     out = {}
@@ -230,11 +282,21 @@ def cpu_secondary_baselines():
         x = x * 5 % q2
         ts.append(x if x < q2 // 2 else x - q2)
     ts = [-5] + ts
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(os.cpu_count() or 1, cref.num_threads(), 16))  # a 1-GPU box's CPU share is 16 cores
+
+    def all_cores(fn):  # one unit per thread, all threads at once (ctypes releases the GIL inside the C oracle)
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda _: fn(), range(threads)))
+            return threads / (time.perf_counter() - t0)
+
     cref.ntt_fwd(q, f, n)  # twiddle set-up outside the timed region
     t0 = time.perf_counter()
     cref.blind_rotate(q, n, w, log_b, d, log_b, d, brk, ak, ts, f, lwe_a, 7)
     dt = time.perf_counter() - t0
-    out["fhew"] = {"blind_rotations_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg3 blind rotation"}
+    out["fhew"] = {"blind_rotations_per_sec": all_cores(lambda: cref.blind_rotate(q, n, w, log_b, d, log_b, d, brk, ak, ts, f, lwe_a, 7)), "cores": threads,
+                   "kind": "port", "single_thread_value": 1.0 / dt, "sample": "%d cfg3 blind rotations, one per thread (the reference is single-threaded: single_thread_value)" % threads}
     # cfg4: one CKKS key switch
     n4, big_l = 1 << 15, 8
     primes = cref.two_adic_primes(60, 16, 2 * big_l)
@@ -246,13 +308,13 @@ def cpu_secondary_baselines():
     t0 = time.perf_counter()
     cref.ckks_key_switch(qs, ps, kb, ka, cb, ca)
     dt = time.perf_counter() - t0
-    out["ckks"] = {"key_switches_per_sec": 1.0 / dt, "cores": 1, "kind": "port", "sample": "1 cfg4 key switch (N=2^15, 8+8 limbs)"}
+    out["ckks"] = {"key_switches_per_sec": all_cores(lambda: cref.ckks_key_switch(qs, ps, kb, ka, cb, ca)), "cores": threads, "kind": "port",
+                   "single_thread_value": 1.0 / dt, "sample": "%d cfg4 key switches (N=2^15, 8+8 limbs), one per thread" % threads}
     # cfg5: gate bootstraps with the reference's own floating-point product (util/src/ring/fft/c64.rs restated)
     n5, n_lwe5, lb5, d5 = 1024, 630, 7, 3
     r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2)  # noqa: E731
     bra, brb, v = r64(n_lwe5, 2 * d5, n5), r64(n_lwe5, 2 * d5, n5), r64(n5)
     ksa, ksb = r64(n5 * 5, n_lwe5), r64(n5 * 5)
-    threads = max(1, min(os.cpu_count() or 1, cref.num_threads(), 16))
     a_raw, b_raw = r64(threads, n_lwe5), r64(threads)
     cref.tfhe_bootstrap(lb5, d5, 4, 5, bra[:2], brb[:2], ksa[:, :2].copy(), ksb, v, a_raw[:1, :2].copy(), b_raw[:1], fft=True)  # twiddle set-up
     t0 = time.perf_counter()
@@ -266,14 +328,34 @@ def cpu_secondary_baselines():
     return out
 
 
-def load_pmc():
-    """Counter figures of the dominant kernel from the committed PMC summary (profiles/pmc_summary.json), if any."""
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+def load_pmc(name="pmc_summary.json"):
+    """Counter figures of the headline kernels from the committed PMC summary (profiles/pmc_summary.json), if any."""
+    p = os.path.join(ROOT, "profiles", name)
     try:
         with open(p) as f:
             return json.load(f)
     except Exception:
         return {}
+
+
+def issue_block(kind, measured_ms, batch, cus, pmc, isa):
+    """roofline.issue: how close the kernel runs to the ceiling of its OWN vector-instruction stream.  The stream (static listing
+    = dynamic: the kernels have no loops) is priced with the per-instruction issue costs of DESIGN.md section 4; a launch gives every
+    SIMD batch * 8 / (4 * CUs) waves; the clock is the effective shader clock of the committed counter run (GRBM_GUI_ACTIVE / 8 /
+    duration), 2.4 GHz if that run has none.  frac_of_valu_ceiling = ceiling time / measured launch time."""
+    entry = next((v for k, v in isa.items() if ("ntt14w_%s_kernel" % kind) in k), None)
+    if not entry:
+        return None
+    cycles = entry["priced_simd_cycles_per_wave"]
+    clock = pmc.get("ntt_%s_effective_clock_mhz" % kind) or 2400.0
+    waves_per_simd = batch * 8.0 / (4.0 * cus)
+    ceiling_ms = cycles * waves_per_simd / (clock * 1e3)
+    return {"valu_insts_per_wave_listing": entry["valu_insts"], "valu_insts_per_wave_counters": pmc.get("ntt_%s_valu_insts_per_wave" % kind),
+            "valu_cycles_per_wave_transform": cycles, "waves_per_simd_per_launch": waves_per_simd, "clock_mhz": clock,
+            "clock_source": "profiles/pmc_summary.json (GRBM_GUI_ACTIVE / 8 / duration of the profiled launches)" if pmc.get("ntt_%s_effective_clock_mhz" % kind) else "2.4 GHz specification (no counter run)",
+            "valu_ceiling_ms": ceiling_ms, "measured_ms": measured_ms, "frac_of_valu_ceiling": ceiling_ms / measured_ms,
+            "wave_cycle_split": pmc.get("ntt_%s_wave_cycle_split" % kind),
+            "source": "profiles/ntt14w_isa.json (tools/isa_hist.py on the shipped listing) priced with DESIGN.md section 4's issue costs"}
 
 
 def sharded_secondary(torch, F, dist, dev, local_rank, rank, world, backend):
@@ -363,6 +445,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the final all_gather of results (not in value)")
     ap.add_argument("--no-fhew", action="store_true", help="skip the secondary figures (ring product, cfg3 FHEW, cfg4 CKKS, cfg5 TFHE)")
+    ap.add_argument("--no-verify-secondary", action="store_true", help="skip the oracle comparison of the secondary blocks (profiling passes)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the control path)")
     ap.add_argument("--single-device", action="store_true",
@@ -480,10 +563,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             sharded = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    secondary_ok = True
     if rank == 0:
         transforms = 2.0 * total * args.steps
         achieved = ALGO_BYTES_PER_NTT * batch / (fwd_ms * 1e-3) / 1e9
+        inv_achieved = ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9
         pmc = load_pmc() if args.batch == BATCH else {}
+        isa = load_pmc("ntt14w_isa.json")
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
             "metric": "NTTs/sec at N=2^14 q~60-bit", "value": transforms / elapsed, "unit": "NTTs/sec",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "preheat_ms": preheat_ms,
@@ -495,17 +582,20 @@ def main():
             "config": {"workload": "cfg2: batched forward+inverse negacyclic NTT, N=2^14, q=%d, batch=%d per GPU, "
                                    "HBM-resident" % (Q, args.batch), "n": n, "q": Q, "batch_per_gpu": args.batch,
                        "parallelism": "batch-sharded x%d, no data-path collective" % n_gpus},
-            "roofline": {"bound": "hbm", "kernel": FWD_KERNEL, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("ntt_fwd_bytes_per_launch"), "traffic_source": "profiles/pmc_summary.json (committed counter run of this "
-                         "kernel, FETCH_SIZE x2 + WRITE_SIZE; not re-measured by this process)" if pmc.get("ntt_fwd_bytes_per_launch") else None,
+            # the dominant kernel of a step is the INVERSE transform (the slower of two launches of equal bytes): `kernel`, `achieved`,
+            # `frac`, `traffic` are its figures; the forward's and the whole step's stand next to them
+            "roofline": {"bound": "hbm", "kernel": INV_KERNEL, "achieved": inv_achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_achieved / HBM_PEAK_GBS,
+                         "traffic": pmc.get("ntt_inv_bytes_per_launch"), "traffic_source": "profiles/pmc_summary.json (committed counter run of this "
+                         "kernel's 4096-polynomial launches, FETCH_SIZE x2 + WRITE_SIZE; not re-measured by this process)" if pmc.get("ntt_inv_bytes_per_launch") else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_NTT * batch,
-                         "avg_launch_ms": fwd_ms, "inv_avg_launch_ms": inv_ms,
-                         "inv_kernel": "ntt14w_inv_kernel<ArithDS<60>, false>",
-                         "inv_achieved": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9,
-                         "inv_frac": ALGO_BYTES_PER_NTT * batch / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "secondary_bound": "VALU issue (64-bit modular butterflies on 32-bit multipliers): see DESIGN.md 4.3; "
-                                            "valu_insts_per_wave from the committed counter run: %s" % pmc.get("ntt_fwd_valu_insts_per_wave")},
+                         "avg_launch_ms": inv_ms, "share_of_step": inv_ms / (fwd_ms + inv_ms),
+                         "fwd_kernel": FWD_KERNEL, "fwd_avg_launch_ms": fwd_ms, "fwd_achieved": achieved, "fwd_frac": achieved / HBM_PEAK_GBS,
+                         "fwd_traffic": pmc.get("ntt_fwd_bytes_per_launch"),
+                         "step_achieved": 2 * ALGO_BYTES_PER_NTT * batch / (elapsed / args.steps) / 1e9,
+                         "step_frac": 2 * ALGO_BYTES_PER_NTT * batch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "issue": issue_block("inv", inv_ms, batch, cus, pmc, isa), "fwd_issue": issue_block("fwd", fwd_ms, batch, cus, pmc, isa),
+                         "secondary_bound": "VALU issue (64-bit modular butterflies on 32-bit multipliers): see DESIGN.md 4.3"},
         }
         prop = torch.cuda.get_device_properties(dev)
         out["device"] = {"name": prop.name, "compute_units": prop.multi_processor_count, "max_clock_mhz": getattr(prop, "clock_rate", 2400000) / 1e3,  # torch builds without the field: the 2.4 GHz specification
@@ -515,10 +605,14 @@ def main():
         if sharded is not None:
             out["sharded"] = sharded
         if n_gpus == 1 and not args.no_fhew:
-            out["ntt_mul"] = ntt_mul_bench(torch, F, dev, local_rank, min(args.batch, 2048))
-            out["fhew"] = fhew_bench(torch, F, dev, local_rank)
-            out["ckks"] = ckks_bench(torch, F, dev, local_rank)
-            out["tfhe"] = tfhe_bench(torch, F, dev, local_rank)
+            vs = not args.no_verify_secondary
+            out["ntt_mul"] = ntt_mul_bench(torch, F, dev, local_rank, min(args.batch, 2048), verify=vs)
+            out["fhew"] = fhew_bench(torch, F, dev, local_rank, verify=vs)
+            out["ckks"] = ckks_bench(torch, F, dev, local_rank, verify=vs)
+            out["tfhe"] = tfhe_bench(torch, F, dev, local_rank, verify=vs)
+            if vs:  # what the secondary blocks time is checked too: one oracle comparison per block, outside its timed region
+                out["verified_secondary"] = {k: out[k].get("verified") for k in ("ntt_mul", "fhew", "ckks", "tfhe")}
+                secondary_ok = all(v is True for v in out["verified_secondary"].values())
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if not args.no_fhew:
@@ -530,8 +624,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if not verified:
-        print("bench.py: VERIFICATION FAILED (see `verification` in the JSON line)", file=sys.stderr)
+    if not verified or not secondary_ok:
+        print("bench.py: VERIFICATION FAILED (see `verification` / `verified_secondary` in the JSON line)", file=sys.stderr)
         sys.exit(1)
 
 

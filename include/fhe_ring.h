@@ -48,6 +48,13 @@ int fhe_last_hip_error(void);
 /* Device scratch of the entry points comes from a private stream-ordered pool per device (never the device's default pool);
  * freed blocks are kept for the next call up to 4 GiB.  fhe_trim() returns everything that is not in use to the driver. */
 int fhe_trim(void);
+/* Lab switches.  Routes that a faster one replaced stay in the library so that tests can compare the two bit for bit; NONE changes a
+ * result.  Each is read ONCE from the environment (FHE_RING_<NAME>) and afterwards only through this call: the library never calls
+ * getenv on a call path.  Names: "NO_EDGE" (key switch at N = 2^15 on whole transforms), "NO_LIMB_MAJOR" (linear dispatch order over
+ * several moduli), "NO_W12" (2^12 / 2^13 rings on the generic kernels), "NO_FUSED_MUL" (ring product as forward + multiplying
+ * inverse), "SMALL_BATCH" (FHEW: 4 coefficients per lane up to this batch, 8 above; -1 = the library's rule).  Unknown name:
+ * FHE_ERR_INVALID. */
+int fhe_set_option(const char *name, long value);
 
 /* Entry points that take a modulus instead of a context (fhe_rq_*, fhe_decompose, fhe_automorphism, fhe_monomial_mul,
  * fhe_lwe_*, fhe_rlwe_sample_extract, fhe_torus_decompose, fhe_tfhe_mod_switch, fhe_tglwe_sample_extract, fhe_tlwe_key_switch)

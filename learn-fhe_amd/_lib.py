@@ -121,6 +121,7 @@ def lib():
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
+        L.fhe_set_option.argtypes = [C.c_char_p, C.c_long]
         u64, dbl = C.c_uint64, C.c_double
         L.fhe_sample_zo.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
         L.fhe_ckks_sk_encrypt.argtypes = [vp, ci, vp, vp, sz, sz, u64, u64, vp, vp, ci, vp]
@@ -148,6 +149,11 @@ def lib():
         L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib
+
+
+def set_option(name: str, value: int) -> None:
+    """fhe_set_option: a lab switch of the library (include/fhe_ring.h); none of them changes a result."""
+    check(lib().fhe_set_option(name.encode(), int(value)), "fhe_set_option(%s)" % name)
 
 
 def check(rc, where):

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "../../include/fhe_ring.h"
@@ -70,10 +73,13 @@ namespace fhe {
 constexpr uint64_t POOL_KEEP_BYTES = uint64_t(4) << 30;
 constexpr int MAX_DEVICES = 64;
 inline hipMemPool_t g_pools[MAX_DEVICES] = {};
-inline hipMemPool_t private_pool(int dev) {
+inline std::mutex &pool_mutex() {
     static std::mutex mu;
+    return mu;
+}
+inline hipMemPool_t private_pool(int dev) {
     if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(pool_mutex());
     if (!g_pools[dev]) {
         hipMemPoolProps props = {};
         props.allocType = hipMemAllocationTypePinned;
@@ -87,6 +93,46 @@ inline hipMemPool_t private_pool(int dev) {
         g_pools[dev] = pool;
     }
     return g_pools[dev];
+}
+}  // namespace fhe
+
+// Lab switches: routes that a faster one replaced stay in the library so that tests can compare the two bit for bit and A/B runs
+// need no second build.  None changes a result.  Each is read from the environment ONCE (FHE_RING_<NAME>, when the library first
+// looks at any of them) and afterwards only changes through fhe_set_option(): no getenv on any call path.
+namespace fhe {
+enum Opt { OPT_NO_EDGE = 0, OPT_NO_LIMB_MAJOR, OPT_NO_W12, OPT_NO_FUSED_MUL, OPT_SMALL_BATCH, OPT_COUNT };
+inline const char *const OPT_NAMES[OPT_COUNT] = {"NO_EDGE", "NO_LIMB_MAJOR", "NO_W12", "NO_FUSED_MUL", "SMALL_BATCH"};
+struct Options {
+    std::atomic<long> v[OPT_COUNT];
+    Options() {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            char name[64] = "FHE_RING_";
+            std::strncat(name, OPT_NAMES[i], sizeof(name) - 10);
+            const char *e = std::getenv(name);
+            v[i].store(e ? std::atol(e) : (i == OPT_SMALL_BATCH ? -1L : 0L), std::memory_order_relaxed);
+        }
+    }
+};
+inline Options &options() {
+    static Options o;
+    return o;
+}
+inline long opt(Opt k) { return options().v[k].load(std::memory_order_relaxed); }
+
+// compute units of a device (cached): dispatch thresholds are stated in workgroup generations of THIS chip, not in literals
+inline int cu_count(int dev) {
+    static std::atomic<int> cache[MAX_DEVICES] = {};
+    if (dev < 0 || dev >= MAX_DEVICES) return 256;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) { (void)hipGetLastError(); c = 256; }
+    cache[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
+inline int current_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    return cu_count(dev);
 }
 }  // namespace fhe
 

@@ -155,12 +155,14 @@ int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uin
 // The 4-per-lane form is the faster kernel per ciphertext (more waves to hide the key-row and LDS latencies behind); the
 // 8-per-lane form wins only where its larger generation (1024 ciphertexts on 256 CUs against 768) saves a whole pass: batches of
 // 769 .. 1024.  (N = 2048 keeps the rule it was measured with: 4 per lane up to 512.)
-constexpr size_t FHEW_SMALL_BATCH = 512;
+// In compute units of the device the call runs on (256 on MI355X: the figures above): a generation of the 4-per-lane form is 3
+// ciphertexts per CU, of the 8-per-lane form 4.
 inline bool small_shape(int log_n, size_t batch) {
-    static const long lab = [] { const char *e = getenv("FHE_RING_SMALL_BATCH"); return e ? atol(e) : -1L; }();  // lab override
+    const long lab = fhe::opt(fhe::OPT_SMALL_BATCH);  // lab override (api_common.hpp)
     if (lab >= 0) return log_n >= 10 && batch <= (size_t)lab;
-    if (log_n == 10) return batch <= 768 || batch > 1024;
-    return log_n >= 10 && batch <= FHEW_SMALL_BATCH;
+    const size_t cus = (size_t)fhe::current_cu_count();
+    if (log_n == 10) return batch <= 3 * cus || batch > 4 * cus;
+    return log_n >= 10 && batch <= 2 * cus;
 }
 
 fhe::FhewKey key_view(const fhe_key *k, bool small = false) {

@@ -28,16 +28,18 @@ int check_transform(const fhe_ctx *ctx, const void *a, size_t n, size_t batch) {
 }
 
 // hipFuncSetAttribute once per (kernel, device), not per launch
-hipError_t set_max_lds(const void *kernel, int bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<const void *, int>> done;
+// `done`: one bit per device, owned by the launch-template instantiation of this kernel -- the attribute is set once per (kernel,
+// device) and every later launch costs one relaxed load (no lock, no lookup)
+hipError_t set_max_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count({kernel, dev})) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done.insert({kernel, dev});
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;
 }
 
@@ -47,8 +49,10 @@ int launch_gen(bool inverse, const fhe::ModDesc *descs, unsigned n_desc, u64 *a,
     // measured on MI355X (tools/ntt_lab.hip): staging through LDS wins for the forward stores, direct 16-byte loads win
     // for the inverse
     auto k = inverse ? fhe::ntt_inv_kernel<A, LOG_N, LOG_E, PPW, PFX, true> : fhe::ntt_fwd_kernel<A, LOG_N, LOG_E, PPW, PFX, false>;
-    if (C::LDS_BYTES > 64 * 1024)
-        HIP_TRY(set_max_lds((const void *)k, (int)C::LDS_BYTES));
+    if (C::LDS_BYTES > 64 * 1024) {
+        static std::atomic<uint64_t> done[2];
+        HIP_TRY(set_max_lds((const void *)k, (int)C::LDS_BYTES, done[inverse ? 1 : 0]));
+    }
     unsigned grid = (unsigned)((subs + PPW - 1) / PPW);
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, a, descs, n_desc, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
@@ -87,24 +91,21 @@ int dispatch_large(bool inv, int log_n, const fhe::ModDesc *d, unsigned nd, u64 
 // workgroups per CU.  AF / AI: the arithmetic policy of each direction (measured, tools/ntt_lab2.hip, 4096 transforms at 60 bits:
 // forward 0.274 ms with the two-operand twiddles (ArithDS) against 0.300 with the 8-byte ones (ArithPM); inverse 0.296 against
 // 0.320 since its first pass runs in diagonal form and nothing spills: ntt14w.hpp).
-inline bool limb_major_disabled() {  // FHE_RING_NO_LIMB_MAJOR=1: A/B switch
-    const char *e = getenv("FHE_RING_NO_LIMB_MAJOR");
-    return e && e[0] == '1';
-}
-inline bool wave_local_small_disabled() {  // FHE_RING_NO_W12=1: A/B switch (2^12 / 2^13 on the generic kernels)
-    const char *e = getenv("FHE_RING_NO_W12");
-    return e && e[0] == '1';
-}
+inline bool limb_major_disabled() { return fhe::opt(fhe::OPT_NO_LIMB_MAJOR) != 0; }       // lab switch (api_common.hpp)
+inline bool wave_local_small_disabled() { return fhe::opt(fhe::OPT_NO_W12) != 0; }       // 2^12 / 2^13 on the generic kernels
+// a launch of the two-workgroups-per-CU kernels spans several generations of workgroups from this size on
+inline size_t several_generations() { return size_t(8) * (size_t)fhe::current_cu_count(); }
 template <class AF, class AI, int R0 = 3>
 int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, int pb, hipStream_t st, fhe::NttIo io) {
     auto k = pb ? (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, true, true, R0> : fhe::ntt14w_inv_kernel<AI, true, false, R0>) : fhe::ntt14w_fwd_kernel<AF, true, R0>)
                 : (inv ? (io.mul ? fhe::ntt14w_inv_kernel<AI, false, true, R0> : fhe::ntt14w_inv_kernel<AI, false, false, R0>) : fhe::ntt14w_fwd_kernel<AF, false, R0>);
-    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>()));
+    static std::atomic<uint64_t> done[8];
+    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>(), done[(pb ? 4 : 0) | (inv ? 2 : 0) | (io.mul ? 1 : 0)]));
     // several moduli: modulus-major dispatch order (ntt14w.hpp, sub_of_block)
     const size_t polys = subs >> pb;
     // (only launches of several generations of workgroups: when the whole launch is resident at once the order is irrelevant, and
     // measured 3 % slower at cfg4 batch 8)
-    const bool by_mod = nd > 1 && nd <= 65535 && polys % nd == 0 && subs >= 2048 && !limb_major_disabled();
+    const bool by_mod = nd > 1 && nd <= 65535 && polys % nd == 0 && subs >= several_generations() && !limb_major_disabled();
     const dim3 grid = by_mod ? dim3((unsigned)(subs / nd), nd) : dim3((unsigned)subs);
     hipLaunchKernelGGL(k, grid, dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, pb, io);
     HIP_TRY(hipGetLastError());
@@ -115,8 +116,9 @@ int launch14(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, 
 template <class A, int R0>
 int launch_mul14(const fhe::ModDesc *d, unsigned nd, u64 *a, size_t subs, hipStream_t st, fhe::NttIo io) {
     auto k = fhe::ntt14w_mul_kernel<A, R0>;
-    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>()));
-    const bool by_mod = nd > 1 && nd <= 65535 && subs % nd == 0 && subs >= 2048 && !limb_major_disabled();
+    static std::atomic<uint64_t> done;
+    HIP_TRY(set_max_lds((const void *)k, (int)fhe::w14::lds_bytes<R0>(), done));
+    const bool by_mod = nd > 1 && nd <= 65535 && subs % nd == 0 && subs >= several_generations() && !limb_major_disabled();
     const dim3 grid = by_mod ? dim3((unsigned)(subs / nd), nd) : dim3((unsigned)subs);
     hipLaunchKernelGGL(k, grid, dim3(fhe::w14::threads<R0>()), fhe::w14::lds_bytes<R0>(), st, a, d, nd, (unsigned)subs, 0, io);
     HIP_TRY(hipGetLastError());
@@ -228,8 +230,7 @@ int ntt_inv_inner15(const ModDesc *descs, unsigned n_desc, u64 *a, size_t batch,
 // with the product on the inverse's load.  io.mul as for ntt_inv_multi; io.src must be null.
 int ntt_mul_multi(const ModDesc *descs, unsigned n_desc, u64 *a, int log_n, size_t batch, hipStream_t st, int pm, NttIo io) {
     if (!io.mul || io.src) return FHE_ERR_INVALID;
-    const char *env = getenv("FHE_RING_NO_FUSED_MUL");  // A/B switch, read per call (the tests toggle it)
-    const bool off = env && env[0] == '1';
+    const bool off = fhe::opt(fhe::OPT_NO_FUSED_MUL) != 0;  // lab switch (api_common.hpp)
     if (log_n >= 13 && log_n <= 15 && !off) {
         if (pm == 60) return dispatch_mul14<ArithDS<60>>(log_n, descs, n_desc, a, batch, st, io);
         if (pm == 54) return dispatch_mul14<ArithDS<54>>(log_n, descs, n_desc, a, batch, st, io);
@@ -296,9 +297,21 @@ int fhe_last_hip_error(void) { return g_last_hip; }
 // hand the library's cached stream-ordered scratch (api_common.hpp: one private pool per device) back to the driver
 int fhe_trim(void) {
     int rc = FHE_OK;
+    std::lock_guard<std::mutex> lock(fhe::pool_mutex());
     for (int dev = 0; dev < fhe::MAX_DEVICES; ++dev)
         if (fhe::g_pools[dev] && hipMemPoolTrimTo(fhe::g_pools[dev], 0) != hipSuccess) rc = FHE_ERR_HIP;
     return rc;
+}
+
+// lab switches (api_common.hpp): name without the FHE_RING_ prefix, upper or lower case
+int fhe_set_option(const char *name, long value) {
+    if (!name) return FHE_ERR_INVALID;
+    for (int i = 0; i < fhe::OPT_COUNT; ++i) {
+        const char *a = name, *b = fhe::OPT_NAMES[i];
+        while (*a && *b && (*a == *b || *a - 32 == *b)) { ++a; ++b; }
+        if (!*a && !*b) { fhe::options().v[i].store(value, std::memory_order_relaxed); return FHE_OK; }
+    }
+    return FHE_ERR_INVALID;
 }
 
 int fhe_is_prime(uint64_t q) { return fhe::is_prime_u64(q) ? 1 : 0; }

@@ -406,11 +406,8 @@ void launch_rescale_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 
     RNS_BOUND(r->K, CALL);
 #undef CALL
 }
-// FHE_RING_NO_EDGE=1: the key switch keeps whole 2^15 transforms (A/B runs and the test that both routes agree bit for bit)
-bool edge_enabled() {
-    const char *e = getenv("FHE_RING_NO_EDGE");
-    return !(e && e[0] == '1');
-}
+// lab switch NO_EDGE: the key switch keeps whole 2^15 transforms (A/B runs and the test that both routes agree bit for bit)
+bool edge_enabled() { return fhe::opt(fhe::OPT_NO_EDGE) == 0; }
 }  // namespace
 
 int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {

@@ -277,9 +277,9 @@ def test_scratch_pool_is_private_and_trimmable(fhe, torch_cuda):
 
 
 @pytest.mark.parametrize("log_n", [12, 13, 14, 15])
-def test_alternative_routes_agree(fhe, cref, torch_cuda, log_n, monkeypatch):
+def test_alternative_routes_agree(fhe, cref, torch_cuda, log_n):
     """2^12 / 2^13 rings run the wave-local kernels (R0 = 1 / 2) and ring products at 2^13 .. 2^15 the fused forward-multiply-inverse
-    kernel; the library keeps the older routes behind environment switches: both must give the same bits, and the oracle's."""
+    kernel; the library keeps the older routes behind lab switches (fhe_set_option): both must give the same bits, and the oracle's."""
     import torch
     n, batch = 1 << log_n, 5
     for q in (cref.two_adic_primes(60, 17, 1)[0], cref.two_adic_primes(54, 17, 1)[0], cref.two_adic_primes(45, 17, 1)[0]):  # two-operand products at 60 bits; Shoup
@@ -290,9 +290,9 @@ def test_alternative_routes_agree(fhe, cref, torch_cuda, log_n, monkeypatch):
         b[0, :] = q - 1
         ctx = fhe.NttContext(q)
         outs = []
-        for env in ({}, {"FHE_RING_NO_W12": "1", "FHE_RING_NO_FUSED_MUL": "1"}):
+        for env in ({}, {"NO_W12": 1, "NO_FUSED_MUL": 1}):
             for k, v in env.items():
-                monkeypatch.setenv(k, v)
+                fhe.set_option(k, v)
             f = torch.from_numpy(a.view(np.int64)).cuda()
             ctx.ntt_(f, n)
             m = torch.from_numpy(a.view(np.int64)).cuda()
@@ -301,7 +301,7 @@ def test_alternative_routes_agree(fhe, cref, torch_cuda, log_n, monkeypatch):
             ctx.intt_(r, n)
             outs.append((f.cpu().numpy().view(np.uint64), m.cpu().numpy().view(np.uint64), r.cpu().numpy().view(np.uint64)))
             for k in env:
-                monkeypatch.delenv(k)
+                fhe.set_option(k, 0)
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         assert np.array_equal(outs[0][2], a) and np.array_equal(outs[1][2], a)
         assert np.array_equal(outs[0][0][1], cref.ntt_fwd(q, a[1], n))

@@ -127,7 +127,7 @@ def test_ckks_key_switch_cfg4(fhe, cref, torch_cuda):
 
 
 @pytest.mark.parametrize("big_l,big_k", [(3, 3), (2, 1), (5, 2), (9, 3)])
-def test_ckks_key_switch_2p15_edge_route(fhe, cref, torch_cuda, big_l, big_k, monkeypatch):
+def test_ckks_key_switch_2p15_edge_route(fhe, cref, torch_cuda, big_l, big_k):
     """N = 2^15 on 60-bit pseudo-Mersenne primes: the key switch runs layer 0 of its transforms inside the extend / rescale kernels
     (rns_kernels.hpp, edge kernels) and 2^14 sub-transforms in between.  Ragged limb counts (predicated instantiations, the K = 1
     shortcut of rescale_k, L above the register bound): bit-equal to the oracle AND to the route with whole 2^15 transforms."""
@@ -140,16 +140,18 @@ def test_ckks_key_switch_2p15_edge_route(fhe, cref, torch_cuda, big_l, big_k, mo
     key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
     b, a = dev(torch_cuda, cb), dev(torch_cuda, ca)
     key.key_switch_(b, a)
-    monkeypatch.setenv("FHE_RING_NO_EDGE", "1")
-    b2, a2 = dev(torch_cuda, cb), dev(torch_cuda, ca)
-    key.key_switch_(b2, a2)
-    monkeypatch.delenv("FHE_RING_NO_EDGE")
+    fhe.set_option("NO_EDGE", 1)
+    try:
+        b2, a2 = dev(torch_cuda, cb), dev(torch_cuda, ca)
+        key.key_switch_(b2, a2)
+    finally:
+        fhe.set_option("NO_EDGE", 0)
     assert np.array_equal(host(b), host(b2)) and np.array_equal(host(a), host(a2))
     eb, ea = cref.ckks_key_switch(qs, ps, kb, ka, cb[0], ca[0])
     assert np.array_equal(host(b)[0], eb) and np.array_equal(host(a)[0], ea)
 
 
-def test_modulus_major_dispatch_large_batches(fhe, cref, torch_cuda, monkeypatch):
+def test_modulus_major_dispatch_large_batches(fhe, cref, torch_cuda):
     """Launches over several moduli that span several generations of workgroups are dispatched modulus by modulus (a 2-D grid,
     ntt14w.hpp `sub_of_block`): N = 2^14 transforms of 512 x 4 limbs against the oracle on a spread sample + round trip on all of
     them, and a batch-32 key switch at N = 2^15 bit-equal to the linear dispatch order and to the oracle."""
@@ -176,10 +178,12 @@ def test_modulus_major_dispatch_large_batches(fhe, cref, torch_cuda, monkeypatch
     key = fhe.CkksKey(rns, dev(torch_cuda, kb), dev(torch_cuda, ka), n)
     b, a2 = dev(torch_cuda, cb), dev(torch_cuda, ca)
     key.key_switch_(b, a2)
-    monkeypatch.setenv("FHE_RING_NO_LIMB_MAJOR", "1")
-    b2, a3 = dev(torch_cuda, cb), dev(torch_cuda, ca)
-    key.key_switch_(b2, a3)
-    monkeypatch.delenv("FHE_RING_NO_LIMB_MAJOR")
+    fhe.set_option("NO_LIMB_MAJOR", 1)
+    try:
+        b2, a3 = dev(torch_cuda, cb), dev(torch_cuda, ca)
+        key.key_switch_(b2, a3)
+    finally:
+        fhe.set_option("NO_LIMB_MAJOR", 0)
     assert np.array_equal(host(b), host(b2)) and np.array_equal(host(a2), host(a3))
     eb, ea = cref.ckks_key_switch(qs, ps, kb, ka, cb[31], ca[31])
     assert np.array_equal(host(b)[31], eb) and np.array_equal(host(a2)[31], ea)

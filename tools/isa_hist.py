@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Instruction-class histogram of one kernel in a hipcc -S listing (static counts of the straight-line code).
-usage: isa_hist.py listing.s 'kernel-name-substring' [more substrings...]"""
+usage: isa_hist.py listing.s [--json out.json] 'kernel-name-substring' [more substrings...]
+--json also writes, per kernel, the VALU count and the stream PRICED with the issue costs of DESIGN.md section 4 (SIMD cycles per
+wave-instruction with every CU busy, tools/microbench_issue.hip): what bench.py reports as roofline.issue."""
 import collections
 import re
 import sys
@@ -46,9 +48,22 @@ def classify(op):
     return "other"
 
 
+# SIMD cycles per wave-instruction, chip full (measured with tools/microbench_issue.hip)
+COST = {"mad64": 4.4, "add64": 4.1, "mul32": 4.1, "mov": 2.4, "add/sub carry": 2.4, "bit/shift": 2.4, "select/compare": 2.4, "other valu": 2.4, "s_nop": 0.7}
+WIDE_SHIFT = ("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64")  # 64-bit shifts cost what v_lshl_add_u64 costs
+
+
 def main():
-    ks, meta = kernels(sys.argv[1])
-    for pat in sys.argv[2:]:
+    import json
+    args = sys.argv[1:]
+    jout = None
+    if "--json" in args:
+        i = args.index("--json")
+        jout = args[i + 1]
+        del args[i:i + 2]
+    ks, meta = kernels(args[0])
+    report = {}
+    for pat in args[1:]:
         for name, body in ks.items():
             if pat not in name:
                 continue
@@ -61,6 +76,13 @@ def main():
                 print("   %-18s %5d" % (k, v))
             top = collections.Counter(ops).most_common(14)
             print("   top opcodes: " + ", ".join("%s %d" % t for t in top))
+            wide = sum(1 for o in ops if o.startswith(WIDE_SHIFT))
+            priced = sum(COST.get(k, 0.0) * v for k, v in cls.items()) + wide * (COST["add64"] - COST["bit/shift"])
+            print("   priced VALU stream: %.0f SIMD cycles per wave (costs of DESIGN.md section 4)" % priced)
+            report[name] = {"vgprs": meta[name][0], "scratch_bytes": meta[name][1], "valu_insts": valu, "classes": dict(cls),
+                            "priced_simd_cycles_per_wave": priced, "cost_table": COST}
+    if jout:
+        json.dump(report, open(jout, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -13,8 +13,8 @@ for bits in (60, 45):
         a = torch.randint(0, pr[0], (batch, n), dtype=torch.int64, device="cuda")
         b = torch.randint(0, pr[0], (batch, n), dtype=torch.int64, device="cuda")
         res = []
-        for off in ("0", "1"):
-            os.environ["FHE_RING_NO_FUSED_MUL"] = off
+        for off in (0, 1):
+            F.set_option("NO_FUSED_MUL", off)
             for _ in range(3): ctx.mul_(a, b, n)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -7,8 +7,8 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-fhew --steps 10 --warmup 2 --preheat-ms 0"
-SEC="--no-cpu-baseline --steps 2 --warmup 1 --preheat-ms 0"
-SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+SEC="--no-cpu-baseline --no-verify-secondary --steps 2 --warmup 1 --preheat-ms 0"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 # kernel-trace stats of THE default bench command (what the driver runs): headline + every secondary workload
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
 echo stats done
