@@ -328,10 +328,11 @@ struct ArithPM {
     // to a pair of 64-bit sums and ONE reduction per MAC_TERMS terms (and one in mac_finish) folds them: 6 instructions + 2
     // adds per term instead of 12 + 1.  Bounds: v < 2^(B+2); u < 2^31 y1 + 2^32 with y1 = multiplicand >> 32.
     //  * B <= 56: multiplicands are forward outputs that may never have been folded (ntt_kernels.hpp: fwd_run), < (2 log2 N + 1) q
-    //    <= 27 q < 2^(B+5), so u < 2^(B+4) + 2^32: 32 terms keep sum u < 2^(B+9) + 2^37 <= 2^63 + 2^37 < 2^64, sum v < 2^(B+7).
+    //    <= 27 q < 2^(B+5), so u < 2^(B+4) + 2^32: T terms keep sum u < T 2^(B+4) + T 2^32 < 2^64 for T = 32 at B <= 54 (2^63 + 2^37),
+    //    T = 16 at B = 55, T = 8 at B = 56; sum v < 2^(B+7).
     //  * B > 56: multiplicands < 2^63, u < 2^62 + 2^32: 3 terms keep sum u < 2^64 and sum v < 2^64 - 2^50.
-    // In both cases v + u 2c < 2^(65 + bits(c)) folds to < 2^B + 2^(2 bits(c) + 6) = q + eps.
-    static constexpr int MAC_TERMS = B <= 56 ? 32 : 3;
+    // In every case v + u 2c < 2^(65 + bits(c)) folds to < 2^B + 2^(2 bits(c) + 6) = q + eps.
+    static constexpr int MAC_TERMS = B <= 54 ? 32 : B == 55 ? 16 : B == 56 ? 8 : 3;
     struct MacAcc { u64 v, u; };
     static __device__ __forceinline__ MacAcc mac_zero() { return MacAcc{0, 0}; }
     static __device__ __forceinline__ u64 mac_in(u64 x, const K &) { return x; }

@@ -76,7 +76,9 @@ fhe::RingConsts ring_consts(const fhe_ctx *c, int) {
 #else
 #define FHEW_POLICY54 fhe::ArithPM<54>
 #endif
-inline bool use_pm54(const fhe_ctx *c, int log_n) { return c->pm_b == 54 && log_n >= 9; }
+// ... and on the 55-bit ones of the reference's own parameter sets (scheme/fhew/examples/multi_key_uint8.rs:15-29: log_q = 55)
+#define FHEW_POLICY55 fhe::ArithDS<55>
+inline int fhew_pm(const fhe_ctx *c, int log_n) { return ((c->pm_b == 54 || c->pm_b == 55) && log_n >= 9) ? c->pm_b : 0; }
 
 #define FHEW_DISPATCH(log_n, ...)                                          \
     switch (log_n) {                                                       \
@@ -123,14 +125,14 @@ int key_prepare(const fhe_ctx *ctx, int log_b, int d, int rows_per_ct, const uin
     if (rc == FHE_OK) rc = fhe::ntt_fwd_device(ctx, ta, log_n, 2 * rows, st);
     if (rc == FHE_OK) {
         FHEW_DISPATCH(log_n, hipLaunchKernelGGL(fhe::key_permute_kernel<fhe::WaveRing<LN>>, dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst, rows,
-                                                 use_pm54(ctx, log_n) ? 54 : 0));
+                                                 fhew_pm(ctx, log_n)));
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     u64 *dst_small = nullptr;
     if (rc == FHE_OK && log_n >= 10) {
         if (hipMalloc((void **)&dst_small, 2 * words * sizeof(u64)) != hipSuccess) rc = FHE_ERR_HIP;
         if (rc == FHE_OK) {
-            const int pm = use_pm54(ctx, log_n) ? 54 : 0;
+            const int pm = fhew_pm(ctx, log_n);
             if (log_n == 10) hipLaunchKernelGGL((fhe::key_permute_kernel<fhe::WaveRing<10, 2>>), dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst_small, rows, pm);
             else hipLaunchKernelGGL((fhe::key_permute_kernel<fhe::WaveRing<11, 2>>), dim3(grid_for(words)), dim3(256), 0, st, ta, tb, dst_small, rows, pm);
             if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
@@ -291,11 +293,19 @@ static int gadget_entry(const fhe_ctx *ctx, const fhe_key *key, size_t index, bo
         if (small) { typedef fhe::WaveRing<LN, 2> WS; GP_LAUNCH_W(AR, WS) }                  \
         else { typedef fhe::WaveRing<LN> WD; GP_LAUNCH_W(AR, WD) }                           \
     }
-    if (use_pm54(ctx, key->log_n)) {
+    const int pmv = fhew_pm(ctx, key->log_n);
+    if (pmv == 54) {
         switch (key->log_n) {
             case 9: GP_LAUNCH(FHEW_POLICY54, 9) break;
             case 10: GP_LAUNCH_BIG(FHEW_POLICY54, 10) break;
             case 11: GP_LAUNCH_BIG(FHEW_POLICY54, 11) break;
+            default: return FHE_ERR_UNSUPPORTED;
+        }
+    } else if (pmv == 55) {
+        switch (key->log_n) {
+            case 9: GP_LAUNCH(FHEW_POLICY55, 9) break;
+            case 10: GP_LAUNCH_BIG(FHEW_POLICY55, 10) break;
+            case 11: GP_LAUNCH_BIG(FHEW_POLICY55, 11) break;
             default: return FHE_ERR_UNSUPPORTED;
         }
     } else {
@@ -537,9 +547,15 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
         else { typedef fhe::WaveRing<LN> WD; BR_LAUNCH_W(AR, WD) }                           \
         break;                                                                               \
     }
-    if (use_pm54(ctx, log_n)) {
+    const int pmv = fhew_pm(ctx, log_n);
+    if (pmv == 54) {
         switch (log_n) {
             BR_CASE(FHEW_POLICY54, 9) BR_CASE_BIG(FHEW_POLICY54, 10) BR_CASE_BIG(FHEW_POLICY54, 11)
+            default: return fail(FHE_ERR_UNSUPPORTED);
+        }
+    } else if (pmv == 55) {
+        switch (log_n) {
+            BR_CASE(FHEW_POLICY55, 9) BR_CASE_BIG(FHEW_POLICY55, 10) BR_CASE_BIG(FHEW_POLICY55, 11)
             default: return fail(FHE_ERR_UNSUPPORTED);
         }
     } else {

@@ -134,12 +134,13 @@ int dispatch_mul14(int log_n, const fhe::ModDesc *d, unsigned nd, u64 *a, size_t
     }
 }
 
-// pm = common bit length of pseudo-Mersenne eligible moduli for which kernels are instantiated (60, 54), else 0
+// pm = common bit length of pseudo-Mersenne eligible moduli; kernels are instantiated for 60, 55 and 54 bits (anything else: Shoup)
 int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_n, size_t subs, int pb, int pm, hipStream_t st, fhe::NttIo io) {
     if (pb && log_n != 14) return FHE_ERR_UNSUPPORTED;
     if (log_n == 15) {  // whole 2^15 rings in one pass over HBM (ntt14w.hpp, R0 = 4): one workgroup of 1024 threads per CU
         if (pm == 60) return launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 4>(inv, d, nd, a, subs, 0, st, io);
         if (pm == 54) return launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 4>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 55) return launch14<fhe::ArithDS<55>, fhe::ArithDS<55>, 4>(inv, d, nd, a, subs, 0, st, io);
         return launch14<fhe::ArithShoup, fhe::ArithShoup, 4>(inv, d, nd, a, subs, 0, st, io);
     }
     if ((log_n == 12 || log_n == 13) && !wave_local_small_disabled()) {
@@ -149,6 +150,8 @@ int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_
                                          : launch14<fhe::ArithDS<60>, fhe::ArithDS<60>, 1>(inv, d, nd, a, subs, 0, st, io);
         if (pm == 54) return log_n == 13 ? launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 2>(inv, d, nd, a, subs, 0, st, io)
                                          : launch14<fhe::ArithDS<54>, fhe::ArithDS<54>, 1>(inv, d, nd, a, subs, 0, st, io);
+        if (pm == 55) return log_n == 13 ? launch14<fhe::ArithDS<55>, fhe::ArithDS<55>, 2>(inv, d, nd, a, subs, 0, st, io)
+                                         : launch14<fhe::ArithDS<55>, fhe::ArithDS<55>, 1>(inv, d, nd, a, subs, 0, st, io);
         return log_n == 13 ? launch14<fhe::ArithShoup, fhe::ArithShoup, 2>(inv, d, nd, a, subs, 0, st, io)
                            : launch14<fhe::ArithShoup, fhe::ArithShoup, 1>(inv, d, nd, a, subs, 0, st, io);
     }
@@ -157,6 +160,9 @@ int sub_transform(bool inv, const fhe::ModDesc *d, unsigned nd, u64 *a, int log_
                                      : dispatch_large<fhe::ArithPM<60>>(inv, log_n, d, nd, a, subs, pb, st, io);
     if (pm == 54) return log_n == 14 ? launch14<fhe::ArithDS<54>, fhe::ArithDS<54>>(inv, d, nd, a, subs, pb, st, io)
                                      : dispatch_large<fhe::ArithPM<54>>(inv, log_n, d, nd, a, subs, pb, st, io);
+    // the reference's own 55-bit parameter sets (scheme/fhew/examples/multi_key_uint8.rs:15-29, util/src/ring/rns.rs:373-386)
+    if (pm == 55) return log_n == 14 ? launch14<fhe::ArithDS<55>, fhe::ArithDS<55>>(inv, d, nd, a, subs, pb, st, io)
+                                     : dispatch_large<fhe::ArithPM<55>>(inv, log_n, d, nd, a, subs, pb, st, io);
     return log_n == 14 ? launch14<fhe::ArithShoup, fhe::ArithShoup>(inv, d, nd, a, subs, pb, st, io)
                        : dispatch_large<fhe::ArithShoup>(inv, log_n, d, nd, a, subs, pb, st, io);
 }

@@ -24,13 +24,19 @@ src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 os.makedirs("profiles", exist_ok=True)
 
 
+def newest(pattern_dir, suffix):
+    """gpurun merges new files into gpurun_out/ without removing older runs': per directory only the most recent file counts"""
+    fs = glob.glob(os.path.join(pattern_dir, "**", "*" + suffix), recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
 def short(name):
     name = re.sub(r"\(.*", "", name)
     return name.replace("void ", "").replace("fhe::", "")[:90]
 
 
 # ---- durations: our own statistics over the kernel TRACE, one row per (kernel, workgroups per launch) ----
-for f in glob.glob(os.path.join(src, "prof_stats*", "**", "*kernel_trace.csv"), recursive=True):
+for f in [x for d in glob.glob(os.path.join(src, "prof_stats*")) if os.path.isdir(d) for x in newest(d, "kernel_trace.csv")]:
     sub = os.path.relpath(f, src).split(os.sep)[0].replace("prof_stats", "")
     groups = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -51,7 +57,7 @@ for f in glob.glob(os.path.join(src, "prof_stats*", "**", "*kernel_trace.csv"), 
 # ---- counters: per (directory, kernel, workgroups per launch) ----
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in glob.glob(os.path.join(src, "*")):
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in (newest(d, "counter_collection.csv") if os.path.isdir(d) else []):
         for r in csv.DictReader(open(f)):
             wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
             key = "%s:%s:wg%d" % (os.path.basename(d), short(r["Kernel_Name"]), wgs)
