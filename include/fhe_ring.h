@@ -278,74 +278,87 @@ int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_
                        uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
 
 /* ---- key material on the device ------------------------------------------------- */
-/* Randomness: value i of a draw is a word of ChaCha20 block (i / words per block) under a key expanded from `seed`, nonce
- * `stream_id` -- counter based, reproducible, order independent.  The reference draws from `thread_rng()`; draws are not
- * parity relevant, these entry points are validated at decrypt level and statistically. */
+/* Randomness.  Every producer below draws from an `fhe_rng`: a 256-bit ChaCha20 key.  Value i of a draw is a word of ChaCha20
+ * block (i / words per block) -- counter based: every GPU lane finds its value without shared state, a draw is reproducible and
+ * order independent -- under a PER-CALL key derived from (generator key, stream_id, the entry point's purpose tag), so different
+ * entry points never share keystream even when a caller reuses a stream id: a secret key drawn with fhe_sample_binary(rng, 7) has
+ * nothing in common with the public mask of fhe_tlwe_sk_encrypt(rng, 7).  What the caller MUST still guarantee: two calls of the
+ * SAME entry point on the same generator use different stream ids (equal ids reproduce the same mask and the same noise:
+ * b1 - b2 = pt1 - pt2).  Pass FHE_STREAM_AUTO to let the generator number the calls itself (fresh id per call, from its own
+ * counter, in the upper half of the id space: keep explicit ids below 2^63 when mixing both).  The reference draws from
+ * `thread_rng()`; draws are not parity relevant, these entry points are validated at decrypt level and statistically.
+ *   fhe_rng_create(key32, &rng): key32 = 32 bytes of caller entropy, or NULL = 32 bytes from the operating system (getrandom),
+ *                                what the reference's thread_rng() is seeded with.
+ *   fhe_rng_create_from_seed:    TESTS AND REPRODUCIBLE RUNS ONLY -- 64 bits of entropy stretched to a key (SplitMix64); keys made
+ *                                from it are as strong as the seed, never stronger.
+ *   fhe_chacha20_block:          the block function alone (host), for known-answer tests: ChaCha20 in the original layout, 64-bit
+ *                                block counter and 64-bit nonce (RFC 8439's function with its 32/96-bit split undone). */
+typedef struct fhe_rng fhe_rng;
+#define FHE_STREAM_AUTO UINT64_MAX
+int fhe_rng_create(const uint8_t *key32, fhe_rng **out);
+int fhe_rng_create_from_seed(uint64_t seed, fhe_rng **out);
+void fhe_rng_destroy(fhe_rng *rng);
+int fhe_chacha20_block(const uint8_t *key32, uint64_t nonce, uint64_t counter, uint8_t *out64);
 /* util/src/zq.rs:91-93 `Zq::sample_uniform`: `count` values uniform in [0, q) */
-int fhe_sample_uniform(uint64_t q, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+int fhe_sample_uniform(uint64_t q, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
 /* util/src/torus.rs `T64::sample_uniform`: uniform 64-bit torus values */
-int fhe_sample_torus(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+int fhe_sample_torus(const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
 /* util/src/misc/distribution.rs:23-46 `dg(std_dev, n)` (weights from the reference's erf approximation, support
  * [-floor(n std_dev), floor(n std_dev)]) as `Zq::sample_i64` (zq.rs:95-97); q = 0: plain two's-complement integers */
-int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
+int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
                   void *stream);
 /* util/src/misc/decompose.rs:35-40 `power_up`: out[p][j] = in[p] * 2^(rounding_bits + j log_b) mod q, [polys][d][n] */
 int fhe_power_up(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, size_t polys, uint64_t *out, fhe_mem mem, void *stream);
 /* scheme/fhew/src/rlwe.rs:146-156 `Rlwe::sk_encrypt` for `batch` plaintexts (pt [batch][n] or NULL = zeros): a uniform,
  * e <- dg(3.2, 6), b = a sk + e + pt.  sk [n]: the secret key as Zq values (`Zq::from_i64` of its coefficients). */
-int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
-                        uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng, uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
 /* scheme/fhew/src/rgsw.rs:84-105 `Rgsw::sk_encrypt` of `count` plaintext polynomials (pt [count][n], `Rgsw::encode`d):
  * rows_a / rows_b [count][2d][n], the layout fhe_rgsw_prepare takes. */
 int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count,
-                     uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+                     const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
 /* scheme/fhew/src/rlwe.rs:109-120 `Rlwe::ksk_gen(param, sk0, sk1)` (t = 0) and 122-132 `Rlwe::ak_gen(param, t, sk0)` (t != 0,
  * sk1 ignored: the key switches sk0(X^t) back to sk0): rows_a / rows_b [d][n], the layout fhe_ksk_prepare takes. */
 int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n,
-                     uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+                     const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
 /* scheme/fhew/src/lwe.rs:128-139 `Lwe::sk_encrypt` for `rows` plaintexts over any modulus q < 2^62 (pt [rows] or NULL = zeros):
  * out_a [rows][n] uniform, out_b[r] = <a[r], sk> + pt[r] + e[r], e <- dg(3.2, 6). */
-int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, uint64_t seed, uint64_t stream_id,
+int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, const fhe_rng *rng, uint64_t stream_id,
                        uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream);
 /* scheme/fhew/src/lwe.rs:108-119 `Lwe::ksk_gen(param, sk0, sk1)`: ksk_a [n1 d][n0], ksk_b [n1 d] (digit-major rows), the layout
  * fhe_lwe_key_switch / fhe_fhew_bootstrap take with n_in = n1, n_out = n0. */
-int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, uint64_t seed,
-                    uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
+int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, const fhe_rng *rng, uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
 /* util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q, in [count][len] (callers used to loop fhe_rq_add) */
 int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream);
 /* ---- CKKS key material (scheme/ckks/src/ckks.rs:139-183, 215-225).  Secret keys are two's-complement i64 vectors. */
 /* util/src/misc/distribution.rs:10-21 `zo(rho)` (ckks.rs:139-141 `Ckks::sk_gen`: rho = 0.5): -1 / +1 / 0 as i64 */
-int fhe_sample_zo(double rho, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+int fhe_sample_zo(double rho, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
 /* ckks.rs:215-225 `Ckks::sk_encrypt` for `batch` plaintexts over qs (extended = 0) or qs ++ ps: b = -(a sk) + e + pt, a uniform,
  * e <- dg(3.2, 6).  pt [batch][limbs][n] or NULL (zeros: ckks.rs:143-146 `pk_gen`); out_b, out_a [batch][limbs][n]. */
-int fhe_ckks_sk_encrypt(const fhe_rns_ctx *rns, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
-                        uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream);
+int fhe_ckks_sk_encrypt(const fhe_rns_ctx *rns, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng, uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream);
 /* ckks.rs:154-161 `Ckks::ksk_gen(param, sk, sk_prime)` -> ksk_b, ksk_a [L+K][n] for fhe_ckks_ksk_prepare.  sk_prime NULL: sk^2
- * (ckks.rs:163-166 `rlk_gen`), squared on the device; `cjk_gen` / `rtk_gen` (ckks.rs:168-183): sk_prime = sk(X^t), t = -1 / 5^j. */
-int fhe_ckks_ksk_gen(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *sk_prime, size_t n, uint64_t seed, uint64_t stream_id,
+ * (ckks.rs:163-166 `rlk_gen`), squared on the device -- exact while n max|sk_i|^2 < q_0 / 2 (every `zo` key), checked: FHE_ERR_INVALID otherwise; `cjk_gen` / `rtk_gen` (ckks.rs:168-183): sk_prime = sk(X^t), t = -1 / 5^j. */
+int fhe_ckks_ksk_gen(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *sk_prime, size_t n, const fhe_rng *rng, uint64_t stream_id,
                      uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream);
 
 /* ---- TFHE key material, k = 1.  Draws are counter based (ChaCha20, as above): reproducible per
- * (seed, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
+ * (generator key, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
 /* util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: torus Gaussian noise (Box-Muller deviate, fractional part scaled by 2^64) */
-int fhe_sample_tdg(double std_dev, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+int fhe_sample_tdg(double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
 /* distribution.rs `binary()` (scheme/tfhe/src/tlwe.rs:96-98 `Tlwe::sk_gen`): one uniform bit per output word */
-int fhe_sample_binary(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
+int fhe_sample_binary(const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
 /* scheme/tfhe/src/tlwe.rs:122-132 `Tlwe::sk_encrypt` for `rows` plaintexts (pt [rows] or NULL): out_a [rows][n], out_b [rows] */
-int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed, uint64_t stream_id,
+int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, const fhe_rng *rng, uint64_t stream_id,
                         uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream);
 /* scheme/tfhe/src/tlwe.rs:100-111 `Tlwe::ksk_gen(param, sk0, sk1)`: ksk_a [n1 d][n0], ksk_b [n1 d] (digit-major), the layout
  * fhe_tlwe_key_switch / fhe_tfhe_bootstrap take with n_in = n1, n_out = n0 */
-int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, uint64_t seed,
-                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
+int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
 /* scheme/tfhe/src/tglwe.rs:91-103 `Tglwe::sk_encrypt`: ct_a uniform, ct_b = ct_a * sk + e + pt, [rows][n]; sk [n] binary; pt NULL = zeros.
  * The product a * sk is the exact integer product of row T. */
-int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed,
-                         uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
 /* scheme/tfhe/src/tggsw.rs:73-88 `Tggsw::sk_encrypt` for `count` plaintext polynomials pt [count][n] (bootstrapping.rs:64-69: the
  * constants z_i): rows_a, rows_b [count][2d][n], the layout fhe_tggsw_prepare takes */
 int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, double std_dev,
-                      uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+                      const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,4 +10,5 @@ from .ring import (BootstrapKey, CkksKey, Fhew, GadgetKey, NttContext, RnsContex
                    tglwe_sample_extract, tlwe_key_switch, torus_decompose,
                    power_up, rgsw_encrypt, rlwe_ksk_gen, rlwe_sk_encrypt, sample_dg, sample_torus, sample_uniform,
                    lwe_ksk_gen, lwe_sk_encrypt, rq_sum,
-                   sample_binary, sample_tdg, sample_zo, tggsw_encrypt, tglwe_sk_encrypt, tlwe_ksk_gen, tlwe_sk_encrypt)
+                   sample_binary, sample_tdg, sample_zo, tggsw_encrypt, tglwe_sk_encrypt, tlwe_ksk_gen, tlwe_sk_encrypt,
+                   Rng, STREAM_AUTO, chacha20_block)

@@ -122,30 +122,35 @@ def lib():
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_trim.argtypes = []
         L.fhe_set_option.argtypes = [C.c_char_p, C.c_long]
+        L.fhe_rng_create.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.fhe_rng_create_from_seed.argtypes = [C.c_uint64, C.POINTER(vp)]
+        L.fhe_rng_destroy.argtypes = [vp]
+        L.fhe_rng_destroy.restype = None
+        L.fhe_chacha20_block.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p]
         u64, dbl = C.c_uint64, C.c_double
-        L.fhe_sample_zo.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
-        L.fhe_ckks_sk_encrypt.argtypes = [vp, ci, vp, vp, sz, sz, u64, u64, vp, vp, ci, vp]
-        L.fhe_ckks_ksk_gen.argtypes = [vp, vp, vp, sz, u64, u64, vp, vp, ci, vp]
-        L.fhe_sample_tdg.argtypes = [dbl, u64, u64, vp, sz, ci, vp]
-        L.fhe_sample_binary.argtypes = [u64, u64, vp, sz, ci, vp]
-        L.fhe_tlwe_sk_encrypt.argtypes = [vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
-        L.fhe_tlwe_ksk_gen.argtypes = [ci, ci, vp, sz, vp, sz, dbl, u64, u64, vp, vp, ci, vp]
-        L.fhe_tglwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
-        L.fhe_tggsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, dbl, u64, u64, vp, vp, ci, vp]
+        L.fhe_sample_zo.argtypes = [dbl, vp, u64, vp, sz, ci, vp]
+        L.fhe_ckks_sk_encrypt.argtypes = [vp, ci, vp, vp, sz, sz, vp, u64, vp, vp, ci, vp]
+        L.fhe_ckks_ksk_gen.argtypes = [vp, vp, vp, sz, vp, u64, vp, vp, ci, vp]
+        L.fhe_sample_tdg.argtypes = [dbl, vp, u64, vp, sz, ci, vp]
+        L.fhe_sample_binary.argtypes = [vp, u64, vp, sz, ci, vp]
+        L.fhe_tlwe_sk_encrypt.argtypes = [vp, vp, sz, sz, dbl, vp, u64, vp, vp, ci, vp]
+        L.fhe_tlwe_ksk_gen.argtypes = [ci, ci, vp, sz, vp, sz, dbl, vp, u64, vp, vp, ci, vp]
+        L.fhe_tglwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, dbl, vp, u64, vp, vp, ci, vp]
+        L.fhe_tggsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, dbl, vp, u64, vp, vp, ci, vp]
         L.fhe_rns_rescale.argtypes = [vp, vp, vp, sz, sz, ci, vp]
         L.fhe_rns_automorphism.argtypes = [vp, C.c_int64, vp, vp, sz, sz, ci, vp]
         L.fhe_ckks_rotate.argtypes = [vp, vp, C.c_int64, vp, vp, sz, ci, vp]
         L.fhe_ckks_mul.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
-        L.fhe_lwe_sk_encrypt.argtypes = [C.c_uint64, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
-        L.fhe_lwe_ksk_gen.argtypes = [C.c_uint64, ci, ci, vp, sz, vp, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_lwe_sk_encrypt.argtypes = [C.c_uint64, vp, vp, sz, sz, vp, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_lwe_ksk_gen.argtypes = [C.c_uint64, ci, ci, vp, sz, vp, sz, vp, C.c_uint64, vp, vp, ci, vp]
         L.fhe_rq_sum.argtypes = [C.c_uint64, vp, sz, sz, vp, ci, vp]
-        L.fhe_sample_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, sz, ci, vp]
-        L.fhe_sample_torus.argtypes = [C.c_uint64, C.c_uint64, vp, sz, ci, vp]
-        L.fhe_sample_dg.argtypes = [C.c_uint64, C.c_double, ci, C.c_uint64, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_sample_uniform.argtypes = [C.c_uint64, vp, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_sample_torus.argtypes = [vp, C.c_uint64, vp, sz, ci, vp]
+        L.fhe_sample_dg.argtypes = [C.c_uint64, C.c_double, ci, vp, C.c_uint64, vp, sz, ci, vp]
         L.fhe_power_up.argtypes = [C.c_uint64, ci, ci, vp, sz, sz, vp, ci, vp]
-        L.fhe_rlwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
-        L.fhe_rgsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
-        L.fhe_rlwe_ksk_gen.argtypes = [vp, ci, ci, vp, vp, C.c_int64, sz, C.c_uint64, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_rlwe_sk_encrypt.argtypes = [vp, vp, vp, sz, sz, vp, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_rgsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, vp, C.c_uint64, vp, vp, ci, vp]
+        L.fhe_rlwe_ksk_gen.argtypes = [vp, ci, ci, vp, vp, C.c_int64, sz, vp, C.c_uint64, vp, vp, ci, vp]
         L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib

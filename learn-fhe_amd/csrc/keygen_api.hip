@@ -2,7 +2,11 @@
 // encryption, RGSW / key-switching / automorphism key generation, all on the device.
 #include <hip/hip_runtime.h>
 
+#include <sys/random.h>
+
 #include <cmath>
+#include <cstring>
+#include <new>
 
 #include "../../include/fhe_ring.h"
 #include "api_common.hpp"
@@ -91,7 +95,51 @@ int gadget_geometry(u64 q, int log_b, int d, int *rounding_bits) {
 
 extern "C" {
 
-int fhe_sample_uniform(uint64_t q, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+// ---- the generator (include/fhe_ring.h) ------------------------------------------------------------------------------------
+int fhe_rng_create(const uint8_t *key32, fhe_rng **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    fhe_rng *r = new (std::nothrow) fhe_rng();
+    if (!r) return FHE_ERR_INVALID;
+    unsigned char buf[32];
+    if (key32) {
+        std::memcpy(buf, key32, 32);
+    } else {  // 256 bits from the operating system, as the reference's thread_rng() is seeded
+        size_t got = 0;
+        while (got < 32) {
+            const ssize_t k = getrandom(buf + got, 32 - got, 0);
+            if (k <= 0) { delete r; return FHE_ERR_UNSUPPORTED; }
+            got += (size_t)k;
+        }
+    }
+    for (int i = 0; i < 8; ++i) r->key[i] = (unsigned)buf[4 * i] | ((unsigned)buf[4 * i + 1] << 8) | ((unsigned)buf[4 * i + 2] << 16) | ((unsigned)buf[4 * i + 3] << 24);
+    *out = r;
+    return FHE_OK;
+}
+int fhe_rng_create_from_seed(uint64_t seed, fhe_rng **out) {  // tests and reproducible runs ONLY: 64 bits of entropy
+    if (!out) return FHE_ERR_INVALID;
+    fhe_rng *r = new (std::nothrow) fhe_rng();
+    if (!r) { *out = nullptr; return FHE_ERR_INVALID; }
+    fhe::seed_to_key(seed, r->key);
+    *out = r;
+    return FHE_OK;
+}
+void fhe_rng_destroy(fhe_rng *rng) { delete rng; }
+// the block function itself, for known-answer tests (host only): key 32 bytes little endian, 64-bit nonce, 64-bit block counter
+int fhe_chacha20_block(const uint8_t *key32, uint64_t nonce, uint64_t counter, uint8_t *out64) {
+    if (!key32 || !out64) return FHE_ERR_INVALID;
+    fhe::ChaChaKey K;
+    for (int i = 0; i < 8; ++i) K.k[i] = (unsigned)key32[4 * i] | ((unsigned)key32[4 * i + 1] << 8) | ((unsigned)key32[4 * i + 2] << 16) | ((unsigned)key32[4 * i + 3] << 24);
+    K.nonce[0] = (unsigned)nonce; K.nonce[1] = (unsigned)(nonce >> 32);
+    unsigned long long w[8];
+    fhe::chacha20_block(K, counter, w);
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 8; ++b) out64[8 * i + b] = (uint8_t)(w[i] >> (8 * b));
+    return FHE_OK;
+}
+
+int fhe_sample_uniform(uint64_t q, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (q < 2 || (q >> 62) || (!out && count)) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -99,11 +147,12 @@ int fhe_sample_uniform(uint64_t q, uint64_t seed, uint64_t stream_id, uint64_t *
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    int rc = sample_uniform_dev(q, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    int rc = sample_uniform_dev(q, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_UNIFORM), 0, mo.d, count, st);
     return rc == FHE_OK ? mo.sync_out(st) : rc;
 }
 
-int fhe_sample_torus(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+int fhe_sample_torus(const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (!out && count) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -111,13 +160,14 @@ int fhe_sample_torus(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t co
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(blocks_words(count))), dim3(256), 0, st, mo.d, count, fhe::chacha_key(seed, stream_id), 0ull);
+    hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(blocks_words(count))), dim3(256), 0, st, mo.d, count, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_TORUS), 0ull);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
 
-int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
+int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem,
                   void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if ((q >> 62) || q == 1 || (!out && count)) return FHE_ERR_INVALID;
     fhe::DgTable T;
     int rc = dg_table_rc(std_dev, n_sigma, &T);
@@ -128,7 +178,7 @@ int fhe_sample_dg(uint64_t q, double std_dev, int n_sigma, uint64_t seed, uint64
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    rc = sample_dg_dev(q, T, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    rc = sample_dg_dev(q, T, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_DG), 0, mo.d, count, st);
     return rc == FHE_OK ? mo.sync_out(st) : rc;
 }
 
@@ -149,8 +199,9 @@ int fhe_power_up(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, siz
     return mo.sync_out(st);
 }
 
-int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed, uint64_t stream_id,
+int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng, uint64_t stream_id,
                         uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = check_ring(ctx, n);
     if (rc != FHE_OK) return rc;
     if (!sk || ((!ct_a || !ct_b) && batch)) return FHE_ERR_INVALID;
@@ -166,15 +217,15 @@ int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *
     src.src = msk.d; src.src_mod = 1;
     rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, wsk.as<u64>(), ilog2(n), 1, st, ctx->pm_b, src);
     unsigned long long cursor = 0;
-    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, wsk.as<u64>(), pt ? mpt.d : nullptr, batch, ma.d, mb.d, n, batch, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, wsk.as<u64>(), pt ? mpt.d : nullptr, batch, ma.d, mb.d, n, batch, fhe::call_key(rng, stream_id, fhe::RNG_RLWE_ENC), &cursor, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
 }
 
 // rgsw.rs:84-105 for `count` plaintext polynomials under one secret key: rows_a / rows_b [count][2d][n]
-int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, uint64_t seed,
-                     uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = check_ring(ctx, n), rb = 0;
     if (rc == FHE_OK) rc = gadget_geometry(ctx->q, log_b, d, &rb);
     if (rc != FHE_OK) return rc;
@@ -194,7 +245,7 @@ int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, c
     rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, sk_eval, ilog2(n), 1, st, ctx->pm_b, src);
     unsigned long long cursor = 0;
     // 2d encryptions of zero per plaintext (rgsw.rs:91-99) ...
-    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, nullptr, 0, ma.d, mb.d, n, rows, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, nullptr, 0, ma.d, mb.d, n, rows, fhe::call_key(rng, stream_id, fhe::RNG_RGSW_ENC), &cursor, st);
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::power_up_kernel, dim3(grid_for(n * count * d)), dim3(256), 0, st, (const u64 *)mpt.d, pw, n, count, d, rb, log_b,
                            fhe::make_barrett(ctx->q), 0);
@@ -211,8 +262,8 @@ int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, c
 }
 
 // rlwe.rs:109-132: key-switching key sk1 -> sk0 (rows encrypt -sk1 base_j under sk0); t != 0: automorphism key, sk1 = sk0(X^t)
-int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n, uint64_t seed,
-                     uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n, const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = check_ring(ctx, n), rb = 0;
     if (rc == FHE_OK) rc = gadget_geometry(ctx->q, log_b, d, &rb);
     if (rc != FHE_OK) return rc;
@@ -235,7 +286,7 @@ int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, 
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     unsigned long long cursor = 0;
-    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, pw, d, ma.d, mb.d, n, d, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = rlwe_sk_encrypt_dev(ctx, sk_eval, pw, d, ma.d, mb.d, n, d, fhe::call_key(rng, stream_id, fhe::RNG_RLWE_KSK), &cursor, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
@@ -243,13 +294,12 @@ int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, 
 
 // scheme/fhew/src/lwe.rs:128-139 for `rows` plaintexts (pt [rows] or NULL = zeros): out_a [rows][n] uniform, out_b [rows]
 static int lwe_encrypt_common(uint64_t q, const u64 *sk, const u64 *pt, const u64 *sk1, size_t n1, int rb, int log_b, size_t n, size_t rows,
-                              uint64_t seed, uint64_t stream_id, u64 *out_a, u64 *out_b, hipStream_t st) {
+                              const fhe::ChaChaKey &K, u64 *out_a, u64 *out_b, hipStream_t st) {
     fhe::DgTable T;
     int rc = dg_table_rc(3.2, 6, &T);
     if (rc != FHE_OK) return rc;
     StreamWs we(rows * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;
-    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
     rc = sample_uniform_dev(q, K, 0, out_a, rows * n, st);
     if (rc == FHE_OK) rc = sample_dg_dev(q, T, K, blocks_uniform(rows * n), we.as<u64>(), rows, st);
     if (rc == FHE_OK) {
@@ -260,8 +310,9 @@ static int lwe_encrypt_common(uint64_t q, const u64 *sk, const u64 *pt, const u6
     return rc;
 }
 
-int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, uint64_t seed, uint64_t stream_id,
+int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, const fhe_rng *rng, uint64_t stream_id,
                        uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (q < 2 || (q >> 62) || !sk || n == 0 || ((!out_a || !out_b) && rows)) return FHE_ERR_INVALID;
     if (rows == 0) return FHE_OK;
     PtrDeviceGuard pguard(out_a, mem);
@@ -269,7 +320,7 @@ int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_
     hipStream_t st = (hipStream_t)stream;
     Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? rows : 0, mem, true, st), ma(out_a, rows * n, mem, false, st), mb(out_b, rows, mem, false, st);
     if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
-    int rc = lwe_encrypt_common(q, msk.d, pt ? mpt.d : nullptr, nullptr, 0, 0, 0, n, rows, seed, stream_id, ma.d, mb.d, st);
+    int rc = lwe_encrypt_common(q, msk.d, pt ? mpt.d : nullptr, nullptr, 0, 0, 0, n, rows, fhe::call_key(rng, stream_id, fhe::RNG_LWE_ENC), ma.d, mb.d, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
@@ -277,8 +328,8 @@ int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_
 
 // scheme/fhew/src/lwe.rs:108-119 `Lwe::ksk_gen(param, sk0, sk1)`: rows r = j n1 + i encrypt -sk1[i] base_j under sk0:
 // ksk_a [n1 d][n0], ksk_b [n1 d], the layout fhe_lwe_key_switch takes (n_in = n1, n_out = n0)
-int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, uint64_t seed,
-                    uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, const fhe_rng *rng, uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rb = 0;
     int rc = gadget_geometry(q, log_b, d, &rb);
     if (rc != FHE_OK) return rc;
@@ -289,7 +340,7 @@ int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0
     const size_t rows = n1 * d;
     Mirror m0(sk0, n0, mem, true, st), m1(sk1, n1, mem, true, st), ma(ksk_a, rows * n0, mem, false, st), mb(ksk_b, rows, mem, false, st);
     if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
-    rc = lwe_encrypt_common(q, m0.d, nullptr, m1.d, n1, rb, log_b, n0, rows, seed, stream_id, ma.d, mb.d, st);
+    rc = lwe_encrypt_common(q, m0.d, nullptr, m1.d, n1, rb, log_b, n0, rows, fhe::call_key(rng, stream_id, fhe::RNG_LWE_KSK), ma.d, mb.d, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;

@@ -1,12 +1,15 @@
 // Key-material producers on the device: a counter-based generator and the reference's
 // samplers, so that bootstrapping / key-switching keys are built in HBM where the hot path consumes them.
 //
-// Randomness.  The reference draws from `thread_rng()` (ChaCha12 behind a thread-local handle), one value after another; a
-// GPU needs every lane to find ITS value without a shared state.  Here value i of a draw is word (i mod 8) of ChaCha20 block
-// (i div 8) under a 256-bit key expanded from the caller's seed and a 64-bit stream id as the nonce (RFC 8439 block function,
-// 64-bit block counter): reproducible, order independent, and a CSPRNG as the reference's generator is.  Draws are NOT
-// parity-relevant (the reference's are unseeded): these producers are validated at decrypt level and statistically.
+// Randomness.  The reference draws from `thread_rng()` (ChaCha12 behind a thread-local handle, seeded with 256 bits of OS entropy),
+// one value after another; a GPU needs every lane to find ITS value without a shared state.  Here value i of a draw is word
+// (i mod 8) of ChaCha20 block (i div 8) (the block function of RFC 8439 in the ORIGINAL layout: 64-bit block counter, 64-bit nonce;
+// known-answer tested on the host, tests/test_abi_cpu.py) under a per-call key derived from an `fhe_rng`'s 256-bit key (the caller's
+// 32 bytes, or getrandom's), the call's stream id and a purpose tag (call_key): reproducible, order independent, and exactly as
+// strong as the key the caller supplied.  Draws are NOT parity-relevant (the reference's are unseeded): these producers are
+// validated at decrypt level and statistically.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include "arith.hpp"
 
@@ -35,18 +38,47 @@ __host__ __device__ inline void chacha20_block(const ChaChaKey &K, unsigned long
     for (int i = 0; i < 8; ++i) out[i] = (unsigned long long)(x[2 * i] + s[2 * i]) | ((unsigned long long)(x[2 * i + 1] + s[2 * i + 1]) << 32);
 }
 
-// seed -> 256-bit key (SplitMix64 expansion: the seed is the caller's entropy, 64 bits of it; a 256-bit entry point is one line away)
-inline ChaChaKey chacha_key(unsigned long long seed, unsigned long long stream_id) {
+// What a draw is FOR.  The key a call draws under is derived from the generator's 256-bit key, the caller's stream id AND this
+// tag (call_key below), so two entry points never share keystream even when a caller reuses (generator, stream id): a secret key
+// sampled with fhe_sample_binary(rng, 7) shares nothing with the public mask of an fhe_tlwe_sk_encrypt(rng, 7).
+enum RngPurpose : unsigned {
+    RNG_SAMPLE_UNIFORM = 1, RNG_SAMPLE_TORUS, RNG_SAMPLE_DG, RNG_SAMPLE_ZO, RNG_SAMPLE_TDG, RNG_SAMPLE_BINARY,
+    RNG_RLWE_ENC, RNG_RGSW_ENC, RNG_RLWE_KSK, RNG_LWE_ENC, RNG_LWE_KSK, RNG_CKKS_ENC, RNG_CKKS_KSK,
+    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC
+};
+}  // namespace fhe
+
+// the generator behind every key-material entry point (include/fhe_ring.h: fhe_rng_create)
+struct fhe_rng {
+    unsigned key[8];                                   // 256 bits: from the caller, or from the operating system
+    mutable std::atomic<unsigned long long> next{0};   // FHE_STREAM_AUTO: a fresh stream id per call
+};
+
+namespace fhe {
+// per-call key = the first 32 bytes of the ChaCha20 block under the generator key with nonce (purpose, "fhek") and the stream id
+// as the block counter: a PRF of (key, stream id, purpose).  Inside a call the block counter partitions that key's stream
+// between the call's draws (mask, noise, ...): distinct blocks of one ChaCha stream are independent.
+inline ChaChaKey call_key(const fhe_rng *rng, unsigned long long stream_id, unsigned purpose) {
+    ChaChaKey M;
+    for (int i = 0; i < 8; ++i) M.k[i] = rng->key[i];
+    M.nonce[0] = purpose; M.nonce[1] = 0x6b656866u;  // "fhek"
+    if (stream_id == ~0ull) stream_id = (1ull << 63) | rng->next.fetch_add(1, std::memory_order_relaxed);  // FHE_STREAM_AUTO
+    unsigned long long w[8];
+    chacha20_block(M, stream_id, w);
     ChaChaKey K;
+    for (int i = 0; i < 4; ++i) { K.k[2 * i] = (unsigned)w[i]; K.k[2 * i + 1] = (unsigned)(w[i] >> 32); }
+    K.nonce[0] = 0; K.nonce[1] = 0;
+    return K;
+}
+// TESTS ONLY (fhe_rng_create_from_seed): 64 bits of entropy stretched to a key by SplitMix64
+inline void seed_to_key(unsigned long long seed, unsigned (&key)[8]) {
     unsigned long long z = seed;
     for (int i = 0; i < 4; ++i) {
         z += 0x9E3779B97F4A7C15ull;
         unsigned long long v = z;
         v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull; v = (v ^ (v >> 27)) * 0x94D049BB133111EBull; v ^= v >> 31;
-        K.k[2 * i] = (unsigned)v; K.k[2 * i + 1] = (unsigned)(v >> 32);
+        key[2 * i] = (unsigned)v; key[2 * i + 1] = (unsigned)(v >> 32);
     }
-    K.nonce[0] = (unsigned)stream_id; K.nonce[1] = (unsigned)(stream_id >> 32);
-    return K;
 }
 
 // util/src/zq.rs:91-93 `Zq::sample_uniform` (rand's `Uniform::new(0, q)`): uniform in [0, q).  Two 64-bit words per value, reduced
@@ -192,6 +224,16 @@ FHE_HEADER_KERNEL void ckks_finish_b_kernel(u64 *__restrict__ b, const u64 *__re
         if (pt) r = csub(r + pt[((c % pt_batch) * limbs + l) * n + i], q);
         b[idx] = r;
     }
+}
+// max |x_i| of a two's-complement i64 vector, atomically into *out (a bound check on secret keys; set-up code)
+FHE_HEADER_KERNEL void max_abs_i64_kernel(const u64 *__restrict__ in, size_t n, unsigned long long *out) {
+    unsigned long long m = 0;
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const long long v = (long long)in[i];
+        const unsigned long long a = v < 0 ? (unsigned long long)0 - (unsigned long long)v : (unsigned long long)v;
+        m = a > m ? a : m;
+    }
+    atomicMax(out, m);
 }
 // centred lift of a polynomial mod q to two's-complement i64 (the integer square of a small secret key, ckks.rs:78-80)
 FHE_HEADER_KERNEL void centre_to_i64_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t n, u64 q) {

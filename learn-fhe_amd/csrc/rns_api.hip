@@ -745,7 +745,7 @@ int ckks_sk_encrypt_dev(const fhe_rns_ctx *r, int limbs, const u64 *sk, const u6
             if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
         }
     fhe::DgTable T;
-    (void)fhe::make_dg_table(3.2, 6, &T);  // dg(3.2, 6): 39 entries
+    if (rc == FHE_OK && !fhe::make_dg_table(3.2, 6, &T)) rc = FHE_ERR_UNSUPPORTED;  // dg(3.2, 6): 39 entries
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::sample_dg_kernel, dim3(grid_for((batch * n + 7) / 8)), dim3(256), 0, st, e, batch * n, (u64)0, T, K, *cursor);
         *cursor += (batch * n + 7) / 8;
@@ -780,7 +780,8 @@ int ckks_ring_ok(const fhe_rns_ctx *r, size_t n) {
 extern "C" {
 
 // util/src/misc/distribution.rs:10-21 `zo(rho)` as two's-complement i64 (ckks.rs:139-141 `Ckks::sk_gen`: rho = 0.5)
-int fhe_sample_zo(double rho, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+int fhe_sample_zo(double rho, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (!(rho >= 0 && rho <= 1.0) || (!out && count)) return FHE_ERR_INVALID;  // `assert!(rho <= 1.0)`
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -788,15 +789,15 @@ int fhe_sample_zo(double rho, uint64_t seed, uint64_t stream_id, uint64_t *out, 
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    hipLaunchKernelGGL(fhe::sample_zo_kernel, dim3(grid_for((count + 7) / 8)), dim3(256), 0, st, mo.d, count, rho, fhe::chacha_key(seed, stream_id), 0ull);
+    hipLaunchKernelGGL(fhe::sample_zo_kernel, dim3(grid_for((count + 7) / 8)), dim3(256), 0, st, mo.d, count, rho, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_ZO), 0ull);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
 
 // scheme/ckks/src/ckks.rs:215-225 `Ckks::sk_encrypt` for `batch` plaintexts over qs (extended = 0) or qs ++ ps: sk [n] i64;
 // pt [batch][limbs][n] or NULL (zeros: ckks.rs:143-146 `pk_gen`); out_b, out_a [batch][limbs][n], coefficient domain
-int fhe_ckks_sk_encrypt(const fhe_rns_ctx *r, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, uint64_t seed,
-                        uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream) {
+int fhe_ckks_sk_encrypt(const fhe_rns_ctx *r, int extended, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng, uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = ckks_ring_ok(r, n);
     if (rc != FHE_OK) return rc;
     if (!sk || ((!out_b || !out_a) && batch)) return FHE_ERR_INVALID;
@@ -809,7 +810,7 @@ int fhe_ckks_sk_encrypt(const fhe_rns_ctx *r, int extended, const uint64_t *sk, 
     Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? words : 0, mem, true, st), mb(out_b, words, mem, false, st), ma(out_a, words, mem, false, st);
     if (msk.rc | mpt.rc | mb.rc | ma.rc) return FHE_ERR_HIP;
     unsigned long long cursor = 0;
-    rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt ? mpt.d : nullptr, batch, mb.d, ma.d, ilog2(n), batch, fhe::chacha_key(seed, stream_id), &cursor, st);
+    rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt ? mpt.d : nullptr, batch, mb.d, ma.d, ilog2(n), batch, fhe::call_key(rng, stream_id, fhe::RNG_CKKS_ENC), &cursor, st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;
@@ -818,8 +819,9 @@ int fhe_ckks_sk_encrypt(const fhe_rns_ctx *r, int extended, const uint64_t *sk, 
 // scheme/ckks/src/ckks.rs:154-161 `Ckks::ksk_gen(param, sk, sk_prime)`: an encryption of sk' * P over qs ++ ps under sk.
 // sk_prime NULL: sk' = sk^2 (ckks.rs:163-166 `rlk_gen`), the integer negacyclic square computed on the device.  For
 // `cjk_gen` / `rtk_gen` (ckks.rs:168-183) pass sk(X^t), t = -1 / 5^j.  ksk_b, ksk_a [L+K][n], what fhe_ckks_ksk_prepare takes.
-int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *sk_prime, size_t n, uint64_t seed, uint64_t stream_id,
+int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *sk_prime, size_t n, const fhe_rng *rng, uint64_t stream_id,
                      uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = ckks_ring_ok(r, n);
     if (rc != FHE_OK) return rc;
     if (!sk || !ksk_b || !ksk_a) return FHE_ERR_INVALID;
@@ -830,11 +832,20 @@ int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *s
     const size_t words = size_t(limbs) * n;
     Mirror msk(sk, n, mem, true, st), msp(sk_prime, sk_prime ? n : 0, mem, true, st), mb(ksk_b, words, mem, false, st), ma(ksk_a, words, mem, false, st);
     if (msk.rc | msp.rc | mb.rc | ma.rc) return FHE_ERR_HIP;
-    StreamWs ws((words + 2 * n + limbs) * sizeof(u64), st);
+    StreamWs ws((words + 2 * n + limbs + 1) * sizeof(u64), st);
     if (ws.rc != FHE_OK) return ws.rc;
-    u64 *pt = ws.as<u64>(), *sq = pt + words, *d_pm = sq + 2 * n;
+    u64 *pt = ws.as<u64>(), *sq = pt + words, *d_pm = sq + 2 * n, *d_max = d_pm + limbs;
     const u64 *spr = msp.d;
-    if (!sk_prime) {  // sk^2 over Z: |coefficient| <= n, far below q_0 / 2, so the square mod q_0 lifts back exactly
+    unsigned long long sk_max = 0;
+    if (!sk_prime) {
+        // sk^2 over Z is computed mod q_0 and lifted back centred: exact only while n max|sk_i|^2 < q_0 / 2 (ternary keys from
+        // fhe_sample_zo: |coefficient| <= n).  The bound is CHECKED on the device: any other key is an error, not a wrong key.
+        if (hipMemsetAsync(d_max, 0, sizeof(u64), st) != hipSuccess) rc = FHE_ERR_HIP;
+        if (rc == FHE_OK) {
+            hipLaunchKernelGGL(fhe::max_abs_i64_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const u64 *)msk.d, n, (unsigned long long *)d_max);
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+        if (rc == FHE_OK && hipMemcpyAsync(&sk_max, d_max, sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) rc = FHE_ERR_HIP;
         hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const u64 *)msk.d, sq, n, 1, (const fhe::Barrett *)r->d_barrett,
                            (const u64 *)nullptr);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
@@ -856,13 +867,17 @@ int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *s
     for (int l = 0; l < limbs; ++l) pm[l] = prod_mod(r->ps, -1, l < r->L ? r->qs[l] : r->ps[l - r->L]);
     if (rc == FHE_OK && hipMemcpyAsync(d_pm, pm.data(), limbs * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
     if (rc == FHE_OK && hipStreamSynchronize(st) != hipSuccess) rc = FHE_ERR_HIP;  // pm is a stack-owned vector
+    if (rc == FHE_OK && !sk_prime) {  // n max^2 < q_0 / 2, without overflow
+        const fhe::u128 bound = (fhe::u128)n * sk_max * sk_max;
+        if (sk_max >> 31 || bound >= (fhe::u128)(r->qs[0] / 2)) rc = FHE_ERR_INVALID;
+    }
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(words)), dim3(256), 0, st, spr, pt, n, limbs, (const fhe::Barrett *)r->d_barrett,
                            (const u64 *)d_pm);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     unsigned long long cursor = 0;
-    if (rc == FHE_OK) rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt, 1, mb.d, ma.d, log_n, 1, fhe::chacha_key(seed, stream_id), &cursor, st);
+    if (rc == FHE_OK) rc = ckks_sk_encrypt_dev(r, limbs, msk.d, pt, 1, mb.d, ma.d, log_n, 1, fhe::call_key(rng, stream_id, fhe::RNG_CKKS_KSK), &cursor, st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;

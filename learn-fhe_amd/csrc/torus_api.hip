@@ -563,7 +563,8 @@ int torus_ring_ok(const fhe_torus_ctx *t, size_t n) {
 }  // namespace
 extern "C" {
 
-int fhe_sample_tdg(double std_dev, uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+int fhe_sample_tdg(double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (!(std_dev >= 0) || (!out && count)) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -571,11 +572,12 @@ int fhe_sample_tdg(double std_dev, uint64_t seed, uint64_t stream_id, uint64_t *
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    int rc = sample_tdg_dev(std_dev, fhe::chacha_key(seed, stream_id), 0, mo.d, count, st);
+    int rc = sample_tdg_dev(std_dev, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_TDG), 0, mo.d, count, st);
     return rc == FHE_OK ? mo.sync_out(st) : rc;
 }
 
-int fhe_sample_binary(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+int fhe_sample_binary(const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (!out && count) return FHE_ERR_INVALID;
     if (count == 0) return FHE_OK;
     PtrDeviceGuard pguard(out, mem);
@@ -583,14 +585,15 @@ int fhe_sample_binary(uint64_t seed, uint64_t stream_id, uint64_t *out, size_t c
     hipStream_t st = (hipStream_t)stream;
     Mirror mo(out, count, mem, false, st);
     if (mo.rc != FHE_OK) return mo.rc;
-    hipLaunchKernelGGL(fhe::sample_binary_kernel, dim3(grid_for((count + 511) / 512)), dim3(64), 0, st, mo.d, count, fhe::chacha_key(seed, stream_id), 0ull);
+    hipLaunchKernelGGL(fhe::sample_binary_kernel, dim3(grid_for((count + 511) / 512)), dim3(64), 0, st, mo.d, count, fhe::call_key(rng, stream_id, fhe::RNG_SAMPLE_BINARY), 0ull);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
 
 // scheme/tfhe/src/tlwe.rs:122-132 for `rows` plaintexts: out_a [rows][n] uniform torus, out_b[r] = <a[r], sk> + e + pt[r]
-int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed, uint64_t stream_id,
+int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, const fhe_rng *rng, uint64_t stream_id,
                         uint64_t *out_a, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (!sk || n == 0 || !(std_dev >= 0) || ((!out_a || !out_b) && rows)) return FHE_ERR_INVALID;
     if (rows == 0) return FHE_OK;
     PtrDeviceGuard pguard(out_a, mem);
@@ -600,7 +603,7 @@ int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t
     if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
     StreamWs we(rows * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;
-    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
+    const fhe::ChaChaKey K = fhe::call_key(rng, stream_id, fhe::RNG_TLWE_ENC);
     hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(word_blocks(rows * n))), dim3(256), 0, st, ma.d, rows * n, K, 0ull);
     int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (rc == FHE_OK) rc = sample_tdg_dev(std_dev, K, word_blocks(rows * n), we.as<u64>(), rows, st);
@@ -616,8 +619,8 @@ int fhe_tlwe_sk_encrypt(const uint64_t *sk, const uint64_t *pt, size_t n, size_t
 
 // scheme/tfhe/src/tlwe.rs:100-111 `Tlwe::ksk_gen(param, sk0, sk1)`: rows r = j n1 + i encrypt -sk1[i] 2^(rb + j log_b) under sk0:
 // ksk_a [n1 d][n0], ksk_b [n1 d], the layout fhe_tlwe_key_switch takes
-int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, uint64_t seed,
-                     uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     if (log_b < 1 || d < 1 || log_b * d > 64 || !sk0 || !sk1 || n0 == 0 || n1 == 0 || !ksk_a || !ksk_b || !(std_dev >= 0)) return FHE_ERR_INVALID;
     PtrDeviceGuard pguard(ksk_a, mem);
     if (!pguard.ok) return FHE_ERR_HIP;
@@ -627,7 +630,7 @@ int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uin
     if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
     StreamWs we(rows * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;
-    const fhe::ChaChaKey K = fhe::chacha_key(seed, stream_id);
+    const fhe::ChaChaKey K = fhe::call_key(rng, stream_id, fhe::RNG_TLWE_KSK);
     hipLaunchKernelGGL(fhe::sample_u64_kernel, dim3(grid_for(word_blocks(rows * n0))), dim3(256), 0, st, ma.d, rows * n0, K, 0ull);
     int rc = hipGetLastError() == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (rc == FHE_OK) rc = sample_tdg_dev(std_dev, K, word_blocks(rows * n0), we.as<u64>(), rows, st);
@@ -642,8 +645,8 @@ int fhe_tlwe_ksk_gen(int log_b, int d, const uint64_t *sk0, size_t n0, const uin
 }
 
 // scheme/tfhe/src/tglwe.rs:91-103 (k = 1): ct_a, ct_b [rows][n]; pt [rows][n] or NULL (zeros); sk [n] binary
-int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, uint64_t seed,
-                         uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = torus_ring_ok(t, n);
     if (rc != FHE_OK) return rc;
     if (!sk || !(std_dev >= 0) || ((!ct_a || !ct_b) && rows)) return FHE_ERR_INVALID;
@@ -654,7 +657,7 @@ int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint6
     Mirror msk(sk, n, mem, true, st), mpt(pt, pt ? rows * n : 0, mem, true, st), ma(ct_a, rows * n, mem, false, st), mb(ct_b, rows * n, mem, false, st);
     if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
     unsigned long long cursor = 0;
-    rc = tglwe_sk_encrypt_dev(t, msk.d, pt ? mpt.d : nullptr, rows, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::chacha_key(seed, stream_id), &cursor, st);
+    rc = tglwe_sk_encrypt_dev(t, msk.d, pt ? mpt.d : nullptr, rows, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::call_key(rng, stream_id, fhe::RNG_TGLWE_ENC), &cursor, st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
@@ -663,7 +666,8 @@ int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint6
 // scheme/tfhe/src/tggsw.rs:73-88 (k = 1) for `count` plaintext polynomials pt [count][n]: rows_a, rows_b [count][2d][n], the
 // layout fhe_tggsw_prepare takes
 int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, double std_dev,
-                      uint64_t seed, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+                      const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
     int rc = torus_ring_ok(t, n);
     if (rc != FHE_OK) return rc;
     if (log_b < 1 || d < 1 || log_b * d > 64 || !sk || !(std_dev >= 0) || ((!pt || !rows_a || !rows_b) && count)) return FHE_ERR_INVALID;
@@ -675,7 +679,7 @@ int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     Mirror msk(sk, n, mem, true, st), mpt(pt, count * n, mem, true, st), ma(rows_a, rows * n, mem, false, st), mb(rows_b, rows * n, mem, false, st);
     if (msk.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
     unsigned long long cursor = 0;
-    rc = tglwe_sk_encrypt_dev(t, msk.d, nullptr, 0, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::chacha_key(seed, stream_id), &cursor, st);
+    rc = tglwe_sk_encrypt_dev(t, msk.d, nullptr, 0, ma.d, mb.d, ilog2(n), rows, std_dev, fhe::call_key(rng, stream_id, fhe::RNG_TGGSW_ENC), &cursor, st);
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::tggsw_add_gadget_kernel, dim3(grid_for(count * d * n)), dim3(256), 0, st, ma.d, mb.d, (const u64 *)mpt.d, n, count, d,
                            64 - log_b * d, log_b);

@@ -395,7 +395,7 @@ class RnsContext:
         pp = _buf(pt)[0] if pt is not None else None
         limbs = self.L + self.K if extended else self.L
         b, a = _like(sk, (batch, limbs, n)), _like(sk, (batch, limbs, n))
-        L.check(L.lib().fhe_ckks_sk_encrypt(self._h, int(extended), ps, pp, n, batch, seed, stream_id, _buf(b)[0], _buf(a)[0], mem, st),
+        L.check(L.lib().fhe_ckks_sk_encrypt(self._h, int(extended), ps, pp, n, batch, _rng(seed), stream_id, _buf(b)[0], _buf(a)[0], mem, st),
                 "fhe_ckks_sk_encrypt")
         return b, a
 
@@ -404,7 +404,7 @@ class RnsContext:
         ps, _, mem, st = _buf(sk)
         pp = _buf(sk_prime)[0] if sk_prime is not None else None
         kb, ka = _like(sk, (self.L + self.K, n)), _like(sk, (self.L + self.K, n))
-        L.check(L.lib().fhe_ckks_ksk_gen(self._h, ps, pp, n, seed, stream_id, _buf(kb)[0], _buf(ka)[0], mem, st), "fhe_ckks_ksk_gen")
+        L.check(L.lib().fhe_ckks_ksk_gen(self._h, ps, pp, n, _rng(seed), stream_id, _buf(kb)[0], _buf(ka)[0], mem, st), "fhe_ckks_ksk_gen")
         return kb, ka
 
     def automorphism(self, limbs, t, n):
@@ -627,18 +627,60 @@ class Fhew:
 # ---- key material on the device ------------------------------------------------------------------
 
 
+STREAM_AUTO = (1 << 64) - 1  # FHE_STREAM_AUTO: the generator numbers the call itself
+
+
+class Rng:
+    """`fhe_rng` (include/fhe_ring.h): the 256-bit ChaCha20 key every key-material producer draws under.  Rng(key=<32 bytes>) takes
+    the caller's entropy, Rng() 32 bytes from the operating system; Rng(seed=<int>) is the 64-bit test / reproducibility form."""
+
+    def __init__(self, key=None, seed=None):
+        h = C.c_void_p()
+        if seed is not None:
+            L.check(L.lib().fhe_rng_create_from_seed(int(seed), C.byref(h)), "fhe_rng_create_from_seed")
+        else:
+            if key is not None and len(key) != 32:
+                raise ValueError("an fhe_rng key is 32 bytes")
+            L.check(L.lib().fhe_rng_create(bytes(key) if key is not None else None, C.byref(h)), "fhe_rng_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            L.lib().fhe_rng_destroy(self._h)
+            self._h = None
+
+
+_SEED_RNGS = {}
+
+
+def _rng(seed):
+    """every wrapper below takes `seed`: an Rng, or an int -- the deterministic test form (one cached generator per value)"""
+    if isinstance(seed, Rng):
+        return seed._h
+    r = _SEED_RNGS.get(int(seed))
+    if r is None:
+        r = _SEED_RNGS[int(seed)] = Rng(seed=int(seed))
+    return r._h
+
+
+def chacha20_block(key: bytes, nonce: int, counter: int) -> bytes:
+    out = C.create_string_buffer(64)
+    L.check(L.lib().fhe_chacha20_block(bytes(key), nonce, counter, out), "fhe_chacha20_block")
+    return out.raw
+
+
 def sample_uniform(q, seed, stream_id, like, shape):
     """util/src/zq.rs:91-93: uniform in [0, q); `like` picks host (numpy) or device (torch) output."""
     out = _like(like, tuple(shape))
     p, cnt, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_uniform(q, seed, stream_id, p, cnt, mem, st), "fhe_sample_uniform")
+    L.check(L.lib().fhe_sample_uniform(q, _rng(seed), stream_id, p, cnt, mem, st), "fhe_sample_uniform")
     return out
 
 
 def sample_torus(seed, stream_id, like, shape):
     out = _like(like, tuple(shape))
     p, cnt, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_torus(seed, stream_id, p, cnt, mem, st), "fhe_sample_torus")
+    L.check(L.lib().fhe_sample_torus(_rng(seed), stream_id, p, cnt, mem, st), "fhe_sample_torus")
     return out
 
 
@@ -646,7 +688,7 @@ def sample_dg(q, std_dev, n_sigma, seed, stream_id, like, shape):
     """util/src/misc/distribution.rs:23-46 `dg(std_dev, n)` as Zq values (q = 0: two's-complement integers)."""
     out = _like(like, tuple(shape))
     p, cnt, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_dg(q, float(std_dev), n_sigma, seed, stream_id, p, cnt, mem, st), "fhe_sample_dg")
+    L.check(L.lib().fhe_sample_dg(q, float(std_dev), n_sigma, _rng(seed), stream_id, p, cnt, mem, st), "fhe_sample_dg")
     return out
 
 
@@ -667,7 +709,7 @@ def rlwe_sk_encrypt(ctx: NttContext, sk, pt, n, batch, seed, stream_id):
     a, b = _like(sk, (batch, n)), _like(sk, (batch, n))
     pa, _, _, _ = _buf(a)
     pb, _, _, _ = _buf(b)
-    L.check(L.lib().fhe_rlwe_sk_encrypt(ctx.handle, ps, pp, n, batch, seed, stream_id, pa, pb, mem, st), "fhe_rlwe_sk_encrypt")
+    L.check(L.lib().fhe_rlwe_sk_encrypt(ctx.handle, ps, pp, n, batch, _rng(seed), stream_id, pa, pb, mem, st), "fhe_rlwe_sk_encrypt")
     return a, b
 
 
@@ -679,7 +721,7 @@ def rgsw_encrypt(ctx: NttContext, log_b, d, sk, pt, n, seed, stream_id):
     ra, rb = _like(sk, (count, 2 * d, n)), _like(sk, (count, 2 * d, n))
     pa, _, _, _ = _buf(ra)
     pb, _, _, _ = _buf(rb)
-    L.check(L.lib().fhe_rgsw_encrypt(ctx.handle, log_b, d, ps, pp, n, count, seed, stream_id, pa, pb, mem, st), "fhe_rgsw_encrypt")
+    L.check(L.lib().fhe_rgsw_encrypt(ctx.handle, log_b, d, ps, pp, n, count, _rng(seed), stream_id, pa, pb, mem, st), "fhe_rgsw_encrypt")
     return ra, rb
 
 
@@ -690,7 +732,7 @@ def rlwe_ksk_gen(ctx: NttContext, log_b, d, sk0, sk1, t, n, seed, stream_id):
     ra, rb = _like(sk0, (d, n)), _like(sk0, (d, n))
     pa, _, _, _ = _buf(ra)
     pb, _, _, _ = _buf(rb)
-    L.check(L.lib().fhe_rlwe_ksk_gen(ctx.handle, log_b, d, p0, p1, t, n, seed, stream_id, pa, pb, mem, st), "fhe_rlwe_ksk_gen")
+    L.check(L.lib().fhe_rlwe_ksk_gen(ctx.handle, log_b, d, p0, p1, t, n, _rng(seed), stream_id, pa, pb, mem, st), "fhe_rlwe_ksk_gen")
     return ra, rb
 
 
@@ -701,7 +743,7 @@ def lwe_sk_encrypt(q, sk, pt, n, rows, seed, stream_id):
     a, b = _like(sk, (rows, n)), _like(sk, (rows,))
     pa, _, _, _ = _buf(a)
     pb, _, _, _ = _buf(b)
-    L.check(L.lib().fhe_lwe_sk_encrypt(q, ps, pp, n, rows, seed, stream_id, pa, pb, mem, st), "fhe_lwe_sk_encrypt")
+    L.check(L.lib().fhe_lwe_sk_encrypt(q, ps, pp, n, rows, _rng(seed), stream_id, pa, pb, mem, st), "fhe_lwe_sk_encrypt")
     return a, b
 
 
@@ -712,7 +754,7 @@ def lwe_ksk_gen(q, log_b, d, sk0, sk1, seed, stream_id):
     ka, kb = _like(sk0, (n1 * d, n0)), _like(sk0, (n1 * d,))
     pa, _, _, _ = _buf(ka)
     pb, _, _, _ = _buf(kb)
-    L.check(L.lib().fhe_lwe_ksk_gen(q, log_b, d, p0, n0, p1, n1, seed, stream_id, pa, pb, mem, st), "fhe_lwe_ksk_gen")
+    L.check(L.lib().fhe_lwe_ksk_gen(q, log_b, d, p0, n0, p1, n1, _rng(seed), stream_id, pa, pb, mem, st), "fhe_lwe_ksk_gen")
     return ka, kb
 
 
@@ -729,7 +771,7 @@ def sample_tdg(std_dev, seed, stream_id, like, count):
     """util/src/misc/distribution.rs:49-54"""
     out = _like(like, (count,))
     po, _, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_tdg(std_dev, seed, stream_id, po, count, mem, st), "fhe_sample_tdg")
+    L.check(L.lib().fhe_sample_tdg(std_dev, _rng(seed), stream_id, po, count, mem, st), "fhe_sample_tdg")
     return out
 
 
@@ -737,7 +779,7 @@ def sample_binary(seed, stream_id, like, count):
     """distribution.rs `binary()`"""
     out = _like(like, (count,))
     po, _, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_binary(seed, stream_id, po, count, mem, st), "fhe_sample_binary")
+    L.check(L.lib().fhe_sample_binary(_rng(seed), stream_id, po, count, mem, st), "fhe_sample_binary")
     return out
 
 
@@ -746,7 +788,7 @@ def tlwe_sk_encrypt(sk, pt, n, rows, std_dev, seed, stream_id):
     ps, _, mem, st = _buf(sk)
     pp = _buf(pt)[0] if pt is not None else None
     a, b = _like(sk, (rows, n)), _like(sk, (rows,))
-    L.check(L.lib().fhe_tlwe_sk_encrypt(ps, pp, n, rows, std_dev, seed, stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tlwe_sk_encrypt")
+    L.check(L.lib().fhe_tlwe_sk_encrypt(ps, pp, n, rows, std_dev, _rng(seed), stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tlwe_sk_encrypt")
     return a, b
 
 
@@ -755,7 +797,7 @@ def tlwe_ksk_gen(log_b, d, sk0, sk1, std_dev, seed, stream_id):
     p0, n0, mem, st = _buf(sk0)
     p1, n1, _, _ = _buf(sk1)
     ka, kb = _like(sk0, (n1 * d, n0)), _like(sk0, (n1 * d,))
-    L.check(L.lib().fhe_tlwe_ksk_gen(log_b, d, p0, n0, p1, n1, std_dev, seed, stream_id, _buf(ka)[0], _buf(kb)[0], mem, st), "fhe_tlwe_ksk_gen")
+    L.check(L.lib().fhe_tlwe_ksk_gen(log_b, d, p0, n0, p1, n1, std_dev, _rng(seed), stream_id, _buf(ka)[0], _buf(kb)[0], mem, st), "fhe_tlwe_ksk_gen")
     return ka, kb
 
 
@@ -764,7 +806,7 @@ def tglwe_sk_encrypt(t, sk, pt, n, rows, std_dev, seed, stream_id):
     ps, _, mem, st = _buf(sk)
     pp = _buf(pt)[0] if pt is not None else None
     a, b = _like(sk, (rows, n)), _like(sk, (rows, n))
-    L.check(L.lib().fhe_tglwe_sk_encrypt(t.handle, ps, pp, n, rows, std_dev, seed, stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tglwe_sk_encrypt")
+    L.check(L.lib().fhe_tglwe_sk_encrypt(t.handle, ps, pp, n, rows, std_dev, _rng(seed), stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_tglwe_sk_encrypt")
     return a, b
 
 
@@ -774,7 +816,7 @@ def tggsw_encrypt(t, log_b, d, sk, pt, n, std_dev, seed, stream_id):
     pp, cnt, _, _ = _buf(pt)
     count = cnt // n
     ra, rb = _like(sk, (count, 2 * d, n)), _like(sk, (count, 2 * d, n))
-    L.check(L.lib().fhe_tggsw_encrypt(t.handle, log_b, d, ps, pp, n, count, std_dev, seed, stream_id, _buf(ra)[0], _buf(rb)[0], mem, st), "fhe_tggsw_encrypt")
+    L.check(L.lib().fhe_tggsw_encrypt(t.handle, log_b, d, ps, pp, n, count, std_dev, _rng(seed), stream_id, _buf(ra)[0], _buf(rb)[0], mem, st), "fhe_tggsw_encrypt")
     return ra, rb
 
 
@@ -782,5 +824,5 @@ def sample_zo(rho, seed, stream_id, like, count):
     """util/src/misc/distribution.rs:10-21 as two's-complement i64"""
     out = _like(like, (count,))
     po, _, mem, st = _buf(out)
-    L.check(L.lib().fhe_sample_zo(rho, seed, stream_id, po, count, mem, st), "fhe_sample_zo")
+    L.check(L.lib().fhe_sample_zo(rho, _rng(seed), stream_id, po, count, mem, st), "fhe_sample_zo")
     return out

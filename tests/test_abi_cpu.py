@@ -130,3 +130,55 @@ def test_tiny_moduli_follow_the_reference(fhe):
         g = P.generator(q)
         s = (q - 1 & -(q - 1)).bit_length() - 1
         assert (info["g"], info["s"], info["omega"]) == (g, s, pow(g, (q - 1) >> s, q))
+
+
+def _chacha20_block_py(key: bytes, nonce: int, counter: int) -> bytes:
+    """An independent ChaCha20 block (original layout: 64-bit block counter, 64-bit nonce), plain Python."""
+    import struct
+    m32 = 0xFFFFFFFF
+    rot = lambda x, r: ((x << r) | (x >> (32 - r))) & m32  # noqa: E731
+    s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(struct.unpack("<8I", key)) + [counter & m32, counter >> 32, nonce & m32, nonce >> 32]
+    x = list(s)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & m32; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & m32; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & m32; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & m32; x[b] = rot(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return struct.pack("<16I", *[(a + b) & m32 for a, b in zip(x, s)])
+
+
+def test_chacha20_block_known_answers(fhe):
+    """The generator behind every key-material producer (csrc/keygen_kernels.hpp `chacha20_block`, host-callable through
+    fhe_chacha20_block): the published ChaCha20 test vectors (RFC 8439 appendix A.1 #1 - #3: all-zero key, block counters 0 and 1;
+    key 00..01, counter 1 -- with a zero nonce the original 64/64 layout and the RFC's 32/96 layout coincide), and an independent
+    Python implementation of the block function on random keys, nonces and 64-bit counters (the layout the library uses)."""
+    z = bytes(32)
+    assert fhe.chacha20_block(z, 0, 0).hex() == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                                                 "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    assert fhe.chacha20_block(z, 0, 1).hex() == ("9f07e7be5551387a98ba977c732d080dcb0f29a048e3656912c6533e32ee7aed"
+                                                 "29b721769ce64e43d57133b074d839d531ed1f28510afb45ace10a1f4b794d6f")
+    assert fhe.chacha20_block(bytes(31) + b"\x01", 0, 1).hex() == ("3aeb5224ecf849929b9d828db1ced4dd832025e8018b8160b82284f3c949aa5a"
+                                                                  "8eca00bbb4a73bdad192b5c42f73f2fd4e273644c8b36125a64addeb006c13a0")
+    import random
+    rnd = random.Random(5)
+    for _ in range(50):
+        key = bytes(rnd.getrandbits(8) for _ in range(32))
+        nonce, counter = rnd.getrandbits(64), rnd.getrandbits(64)
+        assert fhe.chacha20_block(key, nonce, counter) == _chacha20_block_py(key, nonce, counter)
+
+
+def test_rng_handles(fhe):
+    """fhe_rng: 32 caller bytes, operating-system entropy (NULL key), the 64-bit test form; wrong sizes and NULL are errors."""
+    r1, r2 = fhe.Rng(key=bytes(range(32))), fhe.Rng()
+    assert r1._h and r2._h
+    with pytest.raises(ValueError):
+        fhe.Rng(key=b"short")
+    lib = fhe.lib()
+    assert lib.fhe_rng_create(None, None) == 1  # FHE_ERR_INVALID
+    out = (C.c_uint64 * 4)()
+    assert lib.fhe_sample_torus(None, 0, out, 4, 0, None) == 1  # no generator: FHE_ERR_INVALID (before anything touches a device)

@@ -261,3 +261,36 @@ def test_tdg_and_tglwe_encrypt(fhe, torch_cuda):
     for r in range(rows):
         noise = (host(b)[r] - cref.torus_mul_exact(host(a)[r], host(s)) - pt[r]).view(np.int64).astype(np.float64) / 2.0 ** 64
         assert abs(noise).max() < 6 * sd and noise.std() > 0.5 * sd
+
+
+def test_rng_domain_separation_and_stream_ids(fhe, torch_cuda):
+    """(generator, stream id) reused ACROSS entry points must not share keystream -- the public mask of an encryption
+    made with the pair a secret key was sampled with reveals nothing of that key -- and the documented contract holds: the same
+    entry point with the same pair reproduces its draw, FHE_STREAM_AUTO never does, a 256-bit key is honoured in full."""
+    like = dev(torch_cuda, U([0]))
+    n, rows = 1024, 4
+    rng = fhe.Rng(key=bytes(range(32)))
+    # raw keystream words under (rng, 7) as fhe_sample_torus sees them, the binary secret key, and the masks of three encryptions
+    words = set(L(host(fhe.sample_torus(rng, 7, like, (4 * n * rows,)))))
+    sk = fhe.sample_binary(rng, 7, like, n)
+    a_tlwe, _ = fhe.tlwe_sk_encrypt(sk, None, n, rows, 2.0 ** -30, rng, 7)
+    t = fhe.TorusContext()
+    a_tglwe, _ = fhe.tglwe_sk_encrypt(t, sk, None, n, rows, 2.0 ** -30, rng, 7)
+    assert not words & set(L(host(a_tlwe))) and not words & set(L(host(a_tglwe))) and not set(L(host(a_tlwe))) & set(L(host(a_tglwe)))
+    # the key's bits are not the low (or any fixed) bit of the mask words drawn with the same pair
+    skb = host(sk).astype(np.uint64) & np.uint64(1)
+    for bit in range(64):
+        agree = float((((host(a_tlwe)[0] >> np.uint64(bit)) & np.uint64(1)) == skb).mean())
+        assert 0.4 < agree < 0.6, (bit, agree)
+    # same entry point, same pair: reproducible; another stream id or another purpose: independent
+    assert np.array_equal(host(fhe.sample_binary(rng, 7, like, n)), host(sk))
+    assert not np.array_equal(host(fhe.sample_binary(rng, 8, like, n)), host(sk))
+    q = 18014398509404161
+    assert not np.array_equal(host(fhe.sample_uniform(q, rng, 7, like, (n,))), host(fhe.sample_torus(rng, 7, like, (n,))) % np.uint64(q))
+    # FHE_STREAM_AUTO: a fresh stream per call
+    x1, x2 = host(fhe.sample_torus(rng, fhe.STREAM_AUTO, like, (n,))), host(fhe.sample_torus(rng, fhe.STREAM_AUTO, like, (n,)))
+    assert not np.array_equal(x1, x2)
+    # all 256 key bits matter: flipping the last one changes every draw; operating-system keys differ from each other
+    other = fhe.Rng(key=bytes(range(31)) + b"\x9f")
+    assert not set(L(host(fhe.sample_torus(other, 7, like, (n,))))) & words
+    assert not np.array_equal(host(fhe.sample_torus(fhe.Rng(), 0, like, (n,))), host(fhe.sample_torus(fhe.Rng(), 0, like, (n,))))
