@@ -148,6 +148,10 @@ typedef struct fhe_bootstrap_key fhe_bootstrap_key;
 int fhe_bootstrap_key_create(const fhe_ctx *ctx, const fhe_key *brk, const fhe_key *ak, const int64_t *ak_t, int w,
                              fhe_bootstrap_key **out);
 void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk);
+/* Waits for everything enqueued on `stream`, then FHE_ERR_INVALID if an asynchronous (device-memory) fhe_blind_rotate /
+ * fhe_fhew_bootstrap on this key met an LWE coefficient that is not an odd residue mod 2n since the word was last cleared, else
+ * FHE_OK; clear != 0 resets the word. */
+int fhe_bootstrap_key_status(const fhe_bootstrap_key *bk, void *stream, int clear);
 /* scheme/fhew/src/bootstrapping.rs:158-209 `blind_rotate(param, brk, ak, f, LweCiphertext(a, b))` for a batch:
  * lwe_a [batch][n_lwe] and lwe_b [batch] are taken mod 2n (after mod_switch_odd); f = LUT polynomial(s),
  * f_stride = 0 (one f) or n (one per ciphertext); out_a/out_b [batch][n] = the rotated accumulator.
@@ -155,8 +159,10 @@ void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk);
  * [batch][n_lwe + n + 2] entries, bit 31 set = automorphism ak[idx], clear = external product brk[idx].
  * lwe_b is reduced mod 2n; every lwe_a entry must already be an ODD residue below 2n (what `mod_switch_odd`, lwe.rs:94-99,
  * produces): anything else makes the reference index out of its log map and panic (bootstrapping.rs:221), here FHE_ERR_INVALID.
- * That check is data dependent, so this entry point (and fhe_fhew_bootstrap, which ends with it) SYNCHRONISES `stream` before
- * it returns, device-memory calls included -- the one exception to "device-memory calls are asynchronous". */
+ * That check is data dependent.  Host-memory calls (and calls that ask for the walk) report it in their return value; DEVICE-memory
+ * calls stay asynchronous like every other entry point -- they return once the work is enqueued and record the condition in a
+ * sticky status word of the bootstrap key, which fhe_bootstrap_key_status reads (the same holds for fhe_fhew_bootstrap, which
+ * ends with this call). */
 int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const uint64_t *lwe_b, const uint64_t *f,
                      size_t f_stride, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream,
                      uint32_t *ops_out, uint32_t *nops_out);
@@ -202,6 +208,10 @@ int fhe_rns_pointwise_mul(const fhe_rns_ctx *rns, int extended, uint64_t *a, con
 /* util/src/ring/rns.rs:83-91 `RnsRq::extend_bases(ps)`: in [batch][L][n] over qs -> out [batch][K][n], the new
  * p-limbs (fast base conversion with the reference's f64 rounding correction, rns.rs:331-345). */
 int fhe_rns_extend_bases(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
+                         void *stream);
+/* util/src/ring/rns.rs:93-97 `RnsRq::switch_bases`: the same polynomial over the OTHER base (extend_bases, old limbs dropped).
+ * to_qs = 0: in [batch][L][n] over qs -> out [batch][K][n] over ps; to_qs != 0: in [batch][K][n] over ps -> out [batch][L][n] over qs. */
+int fhe_rns_switch_bases(const fhe_rns_ctx *rns, int to_qs, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
                          void *stream);
 /* util/src/ring/rns.rs:103-118 `rescale_k(K)` of a polynomial over qs ++ ps: in [batch][L+K][n] -> out [batch][L][n]. */
 int fhe_rns_rescale_k(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,
@@ -259,6 +269,14 @@ int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key,
                                size_t batch, fhe_mem mem, void *stream);
 /* scheme/tfhe/src/bootstrapping.rs:99-104 `mod_switch`: rounding_shr(v, 64 - log2(2 big_n)) for `count` torus values. */
 int fhe_tfhe_mod_switch(const uint64_t *in, uint64_t *out, size_t count, size_t big_n, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tggsw.rs:114-121 `Tggsw::cmux(key[index], ct0, ct1)` = ct0 + external_product(key[index], ct1 - ct0) for `batch`
+ * pairs of TGLWE ciphertexts, [batch][n] each; out may alias ct0 or ct1. */
+int fhe_tggsw_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, const uint64_t *ct0_a, const uint64_t *ct0_b,
+                   const uint64_t *ct1_a, const uint64_t *ct1_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+/* scheme/tfhe/src/tglwe.rs:61-66 `TglweCiphertext::rotate(i)`: both halves times X^i (util/src/ring.rs:299-313 on T64), any
+ * integer i (taken mod 2n); ct, out [batch][n], out != ct. */
+int fhe_tglwe_rotate(const uint64_t *ct_a, const uint64_t *ct_b, size_t n, int64_t i, uint64_t *out_a, uint64_t *out_b, size_t batch,
+                     fhe_mem mem, void *stream);
 /* scheme/tfhe/src/bootstrapping.rs:84-96 `blind_rotate`: n_lwe CMUXes (tggsw.rs:114-121) per ciphertext.  a_tilde
  * [batch][n_lwe], b_tilde [batch]: mod-switched TLWE ciphertexts; v [n]: the encoded test polynomial; out [batch][n]. */
 int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, const uint64_t *a_tilde, const uint64_t *b_tilde,

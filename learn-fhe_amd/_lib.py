@@ -84,12 +84,14 @@ def lib():
         L.fhe_bootstrap_key_create.argtypes = [vp, vp, vp, i64p, ci, C.POINTER(vp)]
         L.fhe_bootstrap_key_destroy.argtypes = [vp]
         L.fhe_bootstrap_key_destroy.restype = None
+        L.fhe_bootstrap_key_status.argtypes = [vp, vp, ci]
         L.fhe_blind_rotate.argtypes = [vp, vp, vp, vp, sz, vp, vp, sz, ci, vp, u32p, u32p]
         L.fhe_rns_ctx_create.argtypes = [u64p, ci, u64p, ci, ci, C.POINTER(vp)]
         L.fhe_rns_ctx_destroy.argtypes = [vp]
         L.fhe_rns_ctx_destroy.restype = None
         L.fhe_rns_extend_bases.argtypes = [vp, vp, vp, sz, sz, ci, vp]
         L.fhe_rns_rescale_k.argtypes = [vp, vp, vp, sz, sz, ci, vp]
+        L.fhe_rns_switch_bases.argtypes = [vp, ci, vp, vp, sz, sz, ci, vp]
         L.fhe_ckks_ksk_prepare.argtypes = [vp, vp, vp, sz, ci, C.POINTER(vp)]
         L.fhe_ckks_key_destroy.argtypes = [vp]
         L.fhe_ckks_key_destroy.restype = None
@@ -117,6 +119,8 @@ def lib():
         L.fhe_tggsw_key_destroy.restype = None
         L.fhe_tggsw_external_product.argtypes = [vp, vp, sz, vp, vp, sz, ci, vp]
         L.fhe_tfhe_mod_switch.argtypes = [vp, vp, sz, sz, ci, vp]
+        L.fhe_tggsw_cmux.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_tglwe_rotate.argtypes = [vp, vp, sz, C.c_int64, vp, vp, sz, ci, vp]
         L.fhe_tfhe_blind_rotate.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_tglwe_sample_extract.argtypes = [vp, vp, sz, sz, vp, vp, sz, ci, vp]
         L.fhe_tlwe_key_switch.argtypes = [ci, ci, vp, vp, vp, vp, sz, sz, vp, vp, sz, ci, vp]

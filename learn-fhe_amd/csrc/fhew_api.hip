@@ -33,6 +33,7 @@ struct fhe_bootstrap_key {
     int w = 0;
     unsigned *d_ak_t = nullptr;  // [w + 1] exponents mod 2N
     unsigned *d_dlog = nullptr;  // [2N]
+    int *d_status = nullptr;     // sticky device-side error word of asynchronous (device-memory) blind rotations: fhe_bootstrap_key_status
 };
 
 namespace {
@@ -467,10 +468,13 @@ int fhe_bootstrap_key_create(const fhe_ctx *ctx, const fhe_key *brk, const fhe_k
     if (e == hipSuccess) e = hipMalloc((void **)&bk->d_dlog, dlog.size() * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemcpy(bk->d_ak_t, t.data(), t.size() * sizeof(unsigned), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(bk->d_dlog, dlog.data(), dlog.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&bk->d_status, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(bk->d_status, 0, sizeof(int));
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         if (bk->d_ak_t) (void)hipFree(bk->d_ak_t);
         if (bk->d_dlog) (void)hipFree(bk->d_dlog);
+        if (bk->d_status) (void)hipFree(bk->d_status);
         delete bk;
         return FHE_ERR_HIP;
     }
@@ -484,6 +488,7 @@ void fhe_bootstrap_key_destroy(fhe_bootstrap_key *bk) {
         DeviceGuard guard(bk->ctx->device);
         if (bk->d_ak_t) (void)hipFree(bk->d_ak_t);
         if (bk->d_dlog) (void)hipFree(bk->d_dlog);
+        if (bk->d_status) (void)hipFree(bk->d_status);
     }
     delete bk;
 }
@@ -514,10 +519,14 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     if (wsp.rc != FHE_OK) return wsp.rc;
     unsigned *ws = wsp.as<unsigned>();
     unsigned *d_ops = ws, *d_nops = ws + batch * max_ops;
-    int *d_err = (int *)(d_nops + batch);
+    // Device-memory calls are ASYNCHRONOUS: the data-dependent check (an even LWE coefficient) lands in the key's sticky status word,
+    // read by fhe_bootstrap_key_status.  Host-memory calls (and calls that ask for the walk) synchronise anyway for their copies
+    // and keep a word of their own.
+    const bool async = mem == FHE_MEM_DEVICE && !(ops_out && nops_out);
+    int *d_err = async ? bk->d_status : (int *)(d_nops + batch);
     int rc = FHE_OK;
     auto fail = [&](int code) { return code; };
-    if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) return fail(FHE_ERR_HIP);
+    if (!async && hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) return fail(FHE_ERR_HIP);
     hipLaunchKernelGGL(fhe::blind_rotate_schedule_kernel, dim3((unsigned)batch), dim3(64), 3 * n_lwe * sizeof(unsigned), st, ma.d,
                        (unsigned)n_lwe, (unsigned)batch, (unsigned)n, (unsigned)bk->w, bk->d_dlog, d_ops, d_nops, max_ops, d_err);
     if (hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
@@ -569,6 +578,7 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
 #undef BR_LAUNCH_W
 #undef BR_CASE
     if (rc != FHE_OK || hipGetLastError() != hipSuccess) return fail(FHE_ERR_HIP);
+    if (async) return FHE_OK;  // (the workspace is stream ordered: released after the kernels above)
     int h_err = 0;
     if (hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(FHE_ERR_HIP);
     if (ops_out && nops_out) {
@@ -581,6 +591,22 @@ int fhe_blind_rotate(const fhe_bootstrap_key *bk, const uint64_t *lwe_a, const u
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;  // h_err (and ops_out) must have arrived
     if (rc == FHE_OK && h_err) rc = FHE_ERR_INVALID;  // an LWE coefficient outside the odd residues mod 2N (bootstrapping.rs:221)
     return rc;
+}
+
+// The sticky status of asynchronous blind rotations on this key: everything enqueued on `stream` so far is waited for, then
+// FHE_ERR_INVALID if any of them met an LWE coefficient outside the odd residues mod 2N (bootstrapping.rs:221), else FHE_OK.
+// clear != 0 resets the word (in stream order).
+int fhe_bootstrap_key_status(const fhe_bootstrap_key *bk, void *stream, int clear) {
+    if (!bk) return FHE_ERR_INVALID;
+    if (bk->ctx->device < 0) return FHE_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(bk->ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, bk->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (clear) HIP_TRY(hipMemsetAsync(bk->d_status, 0, sizeof(int), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return h ? FHE_ERR_INVALID : FHE_OK;
 }
 
 // scheme/fhew/src/bootstrapping.rs:149-155 `Bootstrapping::bootstrap(bk, f, ct)` for a batch, everything device side:
@@ -625,6 +651,8 @@ int fhe_fhew_bootstrap(const fhe_bootstrap_key *bk, uint64_t q_ks, int ks_log_b,
     if (rc == FHE_OK) rc = fhe_rlwe_sample_extract(big_q, ra, rb, n, 0, addend, U(moa.d), U(mob.d), batch, FHE_MEM_DEVICE, stream);
     if (rc == FHE_OK) rc = moa.sync_out(st);
     if (rc == FHE_OK) rc = mob.sync_out(st);
+    // host-memory calls have synchronised for their outputs: report the blind rotation's data-dependent check with them
+    if (rc == FHE_OK && mem == FHE_MEM_HOST) rc = fhe_bootstrap_key_status(bk, stream, 1);
     return rc;
 }
 

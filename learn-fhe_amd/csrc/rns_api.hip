@@ -28,8 +28,8 @@ struct fhe_rns_ctx {
     // every modulus a pseudo-Mersenne prime of ONE bit length: the conversions run as unreduced dot products (rns_kernels.hpp)
     bool pm = false;
     fhe::pd::Uni uni{};
-    fhe::PmSrc s_q2p{}, s_p2q{}, s_p2q_sum{}, s_p2q_diff{}, s_last{};
-    fhe::PmRows r_q2p{}, r_q2p_w{}, r_resc{}, r_resc_edge{}, r_last{};
+    fhe::PmSrc s_q2p{}, s_p2q{}, s_p2q_sum{}, s_p2q_diff{}, s_last{}, s_p2q_plain{};
+    fhe::PmRows r_q2p{}, r_q2p_w{}, r_resc{}, r_resc_edge{}, r_last{}, r_p2q_plain{};
 };
 
 struct fhe_ckks_key {
@@ -233,8 +233,8 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
     const size_t o_lhq = bb.put(lhalf_q), o_lhp = bb.put(lhalf_p), o_lpi = bb.put(lpinv), o_lpis = bb.put(lpinv_s);
     // ---- the pseudo-Mersenne route (rns_kernels.hpp): every linear step folded into the constants of unreduced dot products ----
     r->pm = r->all_pm >= 34 && r->all_pm <= 60;
-    size_t so_q2p = 0, so_p2q = 0, so_sum = 0, so_diff = 0, so_last = 0;
-    RowOffsets ro_q2p{}, ro_q2p_w{}, ro_resc{}, ro_edge{}, ro_last{};
+    size_t so_q2p = 0, so_p2q = 0, so_sum = 0, so_diff = 0, so_last = 0, so_plain = 0;
+    RowOffsets ro_q2p{}, ro_q2p_w{}, ro_resc{}, ro_edge{}, ro_last{}, ro_plain{};
     if (r->pm) {
         const int B = r->all_pm;
         const std::vector<uint64_t> &Q = r->qs, &P = r->ps;
@@ -290,6 +290,14 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
             }
             ro_resc = build_rows(bb, Q, K, M, one, X, z, KC, B);
             ro_edge = build_rows(bb, Q, K, M, one, XS, XD, KC, B);
+            // switch_bases P -> Q on its own (rns.rs:93-97): out_l = sum_j (P/p_j mod q_l) vs_j + u (q_l - P mod q_l)
+            so_plain = build_src(bb, P, inv, zk, zk, B);
+            std::vector<uint64_t> MP(size_t(L) * K), UP(L);
+            for (int l = 0; l < L; ++l) {
+                for (int j = 0; j < K; ++j) MP[size_t(l) * K + j] = prod_mod(P, j, Q[l]);
+                UP[l] = (Q[l] - prod_mod(P, -1, Q[l])) % Q[l];
+            }
+            ro_plain = build_rows(bb, Q, K, MP, UP, z, z, z, B);
         }
         // rescale(): P = the last q-limb, K == 1 (no correction term)
         if (L >= 2) {
@@ -335,6 +343,7 @@ int fhe_rns_ctx_create(const uint64_t *qs, int L, const uint64_t *ps, int K, int
         r->s_p2q_sum = src_view(so_sum, K, base); r->s_p2q_diff = src_view(so_diff, K, base);
         r->r_q2p = rows_view(ro_q2p, base); r->r_q2p_w = rows_view(ro_q2p_w, base);
         r->r_resc = rows_view(ro_resc, base); r->r_resc_edge = rows_view(ro_edge, base);
+        r->s_p2q_plain = src_view(so_plain, K, base); r->r_p2q_plain = rows_view(ro_plain, base);
         if (L >= 2) { r->s_last = src_view(so_last, 1, base); r->r_last = rows_view(ro_last, base); }
     }
     *out = r;
@@ -360,17 +369,22 @@ struct PointwiseGrid {
         g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
     }
 };
-// extend_bases(qs -> ps): in [batch][L][n] -> out [batch][K][n]; `copy` (optional) receives the source limbs
+// the new limbs of extend_bases: qs -> ps (in [batch][L][n] -> out [batch][K][n]) or, `to_qs`, ps -> qs; `copy` (optional) receives the
+// source limbs
 void launch_extend(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st,
-                   u64 *copy = nullptr, size_t copy_bs = 0) {
+                   u64 *copy = nullptr, size_t copy_bs = 0, bool to_qs = false) {
     const dim3 grid(grid_for(n * batch));
+    const int la = to_qs ? r->K : r->L, lb = to_qs ? r->L : r->K;
     if (r->pm) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, r->s_q2p, r->r_q2p, r->K, r->uni, copy, copy_bs)
-        RNS_BOUND(r->L, CALL);
+        const fhe::PmSrc &S = to_qs ? r->s_p2q_plain : r->s_q2p;
+        const fhe::PmRows &R = to_qs ? r->r_p2q_plain : r->r_q2p;
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, S, R, lb, r->uni, copy, copy_bs)
+        RNS_BOUND(la, CALL);
 #undef CALL
     } else {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, r->q2p, copy, copy_bs)
-        RNS_BOUND(r->L, CALL);
+        const fhe::BaseConv &C = to_qs ? r->p2q : r->q2p;
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs)
+        RNS_BOUND(la, CALL);
 #undef CALL
     }
 }
@@ -420,6 +434,23 @@ int fhe_rns_extend_bases(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out
     Mirror mi(in, n * batch * r->L, mem, true, st), mo(out, n * batch * r->K, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
     launch_extend(r, mi.d, size_t(r->L) * n, mo.d, size_t(r->K) * n, n, batch, st);
+    HIP_TRY(hipGetLastError());
+    return mo.sync_out(st);
+}
+
+// util/src/ring/rns.rs:93-97 `RnsRq::switch_bases`: the same polynomial over the OTHER base (extend_bases, old limbs dropped).
+// to_qs = 0: in [batch][L][n] over qs -> out [batch][K][n] over ps; to_qs != 0: in [batch][K][n] over ps -> out [batch][L][n] over qs
+int fhe_rns_switch_bases(const fhe_rns_ctx *r, int to_qs, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t la = to_qs ? r->K : r->L, lb = to_qs ? r->L : r->K;
+    Mirror mi(in, n * batch * la, mem, true, st), mo(out, n * batch * lb, mem, false, st);
+    if (mi.rc | mo.rc) return FHE_ERR_HIP;
+    launch_extend(r, mi.d, la * n, mo.d, lb * n, n, batch, st, nullptr, 0, to_qs != 0);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }

@@ -374,6 +374,55 @@ int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key,
     return rc;
 }
 
+// scheme/tfhe/src/tggsw.rs:114-121 `Tggsw::cmux(b, ct0, ct1)` = ct0 + external_product(b, ct1 - ct0) for `batch` pairs of TGLWE
+// ciphertexts (k = 1) under key[index]: [batch][n] each; out may alias ct0 or ct1.
+int fhe_tggsw_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, const uint64_t *ct0_a, const uint64_t *ct0_b,
+                   const uint64_t *ct1_a, const uint64_t *ct1_b, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem, void *stream) {
+    if (!t || !key || key->t != t || index >= key->count || ((!ct0_a || !ct0_b || !ct1_a || !ct1_b || !out_a || !out_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t n = size_t(1) << key->log_n, words = n * batch;
+    Mirror m0a(ct0_a, words, mem, true, st), m0b(ct0_b, words, mem, true, st), m1a(ct1_a, words, mem, true, st), m1b(ct1_b, words, mem, true, st);
+    Mirror moa(out_a, words, mem, false, st), mob(out_b, words, mem, false, st);
+    if (m0a.rc | m0b.rc | m1a.rc | m1b.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    StreamWs ws(2 * words * sizeof(u64), st);  // the difference, then its external product (in place)
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *da = ws.as<u64>(), *db = da + words;
+    const dim3 grid(grid_for(words));
+    hipLaunchKernelGGL(fhe::torus_addsub_kernel, grid, dim3(256), 0, st, (const u64 *)m1a.d, (const u64 *)m0a.d, da, words, 1);
+    hipLaunchKernelGGL(fhe::torus_addsub_kernel, grid, dim3(256), 0, st, (const u64 *)m1b.d, (const u64 *)m0b.d, db, words, 1);
+    HIP_TRY(hipGetLastError());
+    int rc = launch_cmux(t, key, index, da, db, batch, nullptr, 0, st);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::torus_addsub_kernel, grid, dim3(256), 0, st, (const u64 *)m0a.d, (const u64 *)da, moa.d, words, 0);
+    hipLaunchKernelGGL(fhe::torus_addsub_kernel, grid, dim3(256), 0, st, (const u64 *)m0b.d, (const u64 *)db, mob.d, words, 0);
+    HIP_TRY(hipGetLastError());
+    rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
+// scheme/tfhe/src/tglwe.rs:61-66 `TglweCiphertext::rotate(i)`: both halves times X^i; ct, out [batch][n], out != ct
+int fhe_tglwe_rotate(const uint64_t *ct_a, const uint64_t *ct_b, size_t n, int64_t i, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
+                     void *stream) {
+    PtrDeviceGuard pguard(ct_a, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    if (!is_pow2(n) || (n >> 30) || ((!ct_a || !ct_b || !out_a || !out_b) && batch) || (batch && (ct_a == out_a || ct_b == out_b))) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const int64_t two_n = 2 * (int64_t)n;
+    const unsigned k = (unsigned)(((i % two_n) + two_n) % two_n);  // `X ^ i`: i.rem_euclid(2n) (util/src/ring.rs:380-386)
+    hipStream_t st = (hipStream_t)stream;
+    const size_t words = n * batch;
+    Mirror ma(ct_a, words, mem, true, st), mb(ct_b, words, mem, true, st), moa(out_a, words, mem, false, st), mob(out_b, words, mem, false, st);
+    if (ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
+    hipLaunchKernelGGL(fhe::torus_monomial_kernel, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)ma.d, moa.d, (unsigned)n, batch, k);
+    hipLaunchKernelGGL(fhe::torus_monomial_kernel, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)mb.d, mob.d, (unsigned)n, batch, k);
+    HIP_TRY(hipGetLastError());
+    int rc = moa.sync_out(st);
+    return rc != FHE_OK ? rc : mob.sync_out(st);
+}
+
 // scheme/tfhe/src/bootstrapping.rs:99-104 `mod_switch`: v -> rounding_shr(v, 64 - log2(2 big_n)) for `count` torus values
 int fhe_tfhe_mod_switch(const uint64_t *in, uint64_t *out, size_t count, size_t big_n, fhe_mem mem, void *stream) {
     PtrDeviceGuard pguard(in, mem);

@@ -309,6 +309,22 @@ FHE_HEADER_KERNEL void tlwe_key_switch_kernel(const u64 *__restrict__ ct_a, cons
 }
 
 // util/src/torus-side rounding_shr used by bootstrapping.rs:99-104 `mod_switch`
+// out = x + y (sub = 0) or x - y (sub = 1), wrapping mod 2^64 (util/src/torus.rs:40-60)
+FHE_HEADER_KERNEL void torus_addsub_kernel(const u64 *__restrict__ x, const u64 *__restrict__ y, u64 *__restrict__ out, size_t count, int sub) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) out[i] = sub ? x[i] - y[i] : x[i] + y[i];
+}
+// scheme/tfhe/src/tglwe.rs:61-66 `rotate(i)` = every polynomial times X^i (util/src/ring.rs:299-313, 380-406 on T64): k = i mod 2N,
+// rotate right by k mod N, negate what wraps (and everything once more if k >= N).  in, out [polys][n], in != out
+FHE_HEADER_KERNEL void torus_monomial_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned n, size_t polys, unsigned k) {
+    const size_t total = size_t(n) * polys;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t p = idx / n;
+        const unsigned i = unsigned(idx - p * n), j = (i + k) & (2 * n - 1);  // X^i X^k = X^j, X^n = -1
+        const u64 v = in[idx];
+        out[p * n + (j & (n - 1))] = j >= n ? (u64)0 - v : v;
+    }
+}
+
 FHE_HEADER_KERNEL void torus_rounding_shr_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t count, int bits) {
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < count; idx += size_t(gridDim.x) * blockDim.x)
         out[idx] = (in[idx] + ((u64(1) << bits) >> 1)) >> bits;

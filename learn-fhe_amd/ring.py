@@ -299,8 +299,15 @@ class BootstrapKey:
                                            batch, mem, st), "fhe_fhew_bootstrap")
         return out_a, out_b
 
+    def check(self, like=None, clear=True):
+        """fhe_bootstrap_key_status: device-memory blind rotations / bootstraps are asynchronous; this waits for the stream `like`
+        lives on (torch's current stream for a CUDA tensor) and raises if one of them met an even LWE coefficient."""
+        st = _buf(like)[3] if like is not None else None
+        L.check(L.lib().fhe_bootstrap_key_status(self._h, st, int(clear)), "fhe_bootstrap_key_status")
+
     def blind_rotate(self, lwe_a, lwe_b, f, want_schedule=False):
-        """scheme/fhew/src/bootstrapping.rs:158-209 for a batch: lwe_a [batch][n_lwe], lwe_b [batch], f [n] or [batch][n]."""
+        """scheme/fhew/src/bootstrapping.rs:158-209 for a batch: lwe_a [batch][n_lwe], lwe_b [batch], f [n] or [batch][n].
+        Device tensors: asynchronous, the data-dependent input check is reported by check()."""
         n, n_lwe = self.brk.n, self.brk.count
         pa, cnt, mem, st = _buf(lwe_a)
         pb, batch, _, _ = _buf(lwe_b)
@@ -368,6 +375,15 @@ class RnsContext:
         out = _like(limbs, (batch, self.K, n))
         po, _, _, _ = _buf(out)
         L.check(L.lib().fhe_rns_extend_bases(self._h, p, po, n, batch, mem, st), "fhe_rns_extend_bases")
+        return out
+
+    def switch_bases(self, limbs, n, to_qs=False):
+        """rns.rs:93-97: [batch][L][n] over qs -> [batch][K][n] over ps, or (to_qs) [batch][K][n] over ps -> [batch][L][n] over qs."""
+        p, cnt, mem, st = _buf(limbs)
+        la, lb = (self.K, self.L) if to_qs else (self.L, self.K)
+        batch = cnt // (la * n)
+        out = _like(limbs, (batch, lb, n))
+        L.check(L.lib().fhe_rns_switch_bases(self._h, int(bool(to_qs)), p, _buf(out)[0], n, batch, mem, st), "fhe_rns_switch_bases")
         return out
 
     def rescale_k(self, limbs, n):
@@ -520,6 +536,14 @@ class TggswKey:
         pb, _, _, _ = _buf(ct_b)
         L.check(L.lib().fhe_tggsw_external_product(self.t.handle, self._h, index, pa, pb, cnt // self.n, mem, st),
                 "fhe_tggsw_external_product")
+
+    def cmux(self, index, ct0_a, ct0_b, ct1_a, ct1_b):
+        """scheme/tfhe/src/tggsw.rs:114-121: ct0 + external_product(key[index], ct1 - ct0) -> (a, b), [batch][n]."""
+        p0a, cnt, mem, st = _buf(ct0_a)
+        out_a, out_b = _like(ct0_a, (cnt // self.n, self.n)), _like(ct0_a, (cnt // self.n, self.n))
+        L.check(L.lib().fhe_tggsw_cmux(self.t.handle, self._h, index, p0a, _buf(ct0_b)[0], _buf(ct1_a)[0], _buf(ct1_b)[0], _buf(out_a)[0], _buf(out_b)[0],
+                                       cnt // self.n, mem, st), "fhe_tggsw_cmux")
+        return out_a, out_b
 
     def blind_rotate(self, a_tilde, b_tilde, v):
         """scheme/tfhe/src/bootstrapping.rs:84-96."""
@@ -765,6 +789,14 @@ def rq_sum(q, a, n):
     po, _, _, _ = _buf(out)
     L.check(L.lib().fhe_rq_sum(q, p, n, cnt // n, po, mem, st), "fhe_rq_sum")
     return out
+
+
+def tglwe_rotate(ct_a, ct_b, n, i):
+    """scheme/tfhe/src/tglwe.rs:61-66: (a, b) X^i for [batch][n] ciphertexts."""
+    pa, cnt, mem, st = _buf(ct_a)
+    out_a, out_b = _like(ct_a, (cnt // n, n)), _like(ct_a, (cnt // n, n))
+    L.check(L.lib().fhe_tglwe_rotate(pa, _buf(ct_b)[0], n, int(i), _buf(out_a)[0], _buf(out_b)[0], cnt // n, mem, st), "fhe_tglwe_rotate")
+    return out_a, out_b
 
 
 def sample_tdg(std_dev, seed, stream_id, like, count):

@@ -302,8 +302,14 @@ def test_blind_rotate_vs_oracle_small(fhe, cref, torch_cuda):
     # an even (non-zero) LWE coefficient is `unreachable!()` in the reference (bootstrapping.rs:221)
     bad = lwe_a.copy()
     bad[0, 0] = 4
+    bk.check(dev(torch_cuda, lwe_b))                       # nothing wrong so far
+    with pytest.raises(fhe.FheError):                      # host memory: the call itself reports it
+        bk.blind_rotate(bad, lwe_b, f)
+    d_bad = dev(torch_cuda, bad)
+    bk.blind_rotate(d_bad, dev(torch_cuda, lwe_b), dev(torch_cuda, f))  # device memory: asynchronous, the key's status word records it
     with pytest.raises(fhe.FheError):
-        bk.blind_rotate(dev(torch_cuda, bad), dev(torch_cuda, lwe_b), dev(torch_cuda, f))
+        bk.check(d_bad)
+    bk.check(d_bad)                                        # cleared by the previous query
 
 
 @pytest.mark.parametrize("w", [1, 2, 5, 31])
@@ -525,3 +531,41 @@ def test_fhew_gates_decrypt(fhe, torch_cuda):
     assert decrypt(ev.majority(encrypt(t0), encrypt(t1), encrypt(t2))) == [(x & y) | (y & u) | (u & x) for x, y, u in zip(t0, t1, t2)]
     # a two-level circuit: outputs of one gate are valid inputs of the next (noise refreshed)
     assert decrypt(ev.xor(ev.nand(c0, c1), ev.or_(c0, c1))) == [(1 - (x & y)) ^ (x | y) for x, y in zip(m0, m1)]
+
+
+def test_blind_rotate_is_asynchronous_on_device_memory(fhe, torch_cuda):
+    """Device-memory blind rotations return when their work is enqueued (the data-dependent input check goes to the key's status
+    word, fhe_bootstrap_key_status): the call's host time is a fraction of the kernel's, and two streams overlap -- two batch-64
+    blind rotations (64 of 256 CUs each) on two streams finish in well under twice the time of one."""
+    import time
+    torch = torch_cuda
+    q, n, lb, d, w, n_lwe, batch = 18014398509404161, 1024, 6, 9, 10, 100, 64
+    ctx, bk, brk, ak, ts = _make_bk(fhe, torch_cuda, q, n, lb, d, lb, d, w, n_lwe, seed=160)
+    rng = np.random.Generator(np.random.PCG64(161))
+    lwe_a = dev(torch, rng.integers(0, n, size=(batch, n_lwe), dtype=np.uint64) * 2 + 1)
+    lwe_b = dev(torch, rng.integers(0, 2 * n, size=batch, dtype=np.uint64))
+    f = dev(torch, rand_u64(162, q, n))
+    ref_a, ref_b = bk.blind_rotate(lwe_a, lwe_b, f)  # warm-up (module load, LDS attribute)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    oa, ob = bk.blind_rotate(lwe_a, lwe_b, f)
+    t_call = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_one = time.perf_counter() - t0
+    assert t_call < 0.5 * t_one, (t_call, t_one)           # the call returned long before the GPU finished
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for s_ in (s1, s2):  # first use of a stream: its creation and its first workspace from the pool are not what is measured
+        with torch.cuda.stream(s_):
+            bk.blind_rotate(lwe_a, lwe_b, f)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s1):
+        o1 = bk.blind_rotate(lwe_a, lwe_b, f)
+    with torch.cuda.stream(s2):
+        o2 = bk.blind_rotate(lwe_a, lwe_b, f)
+    torch.cuda.synchronize()
+    t_two = time.perf_counter() - t0
+    assert t_two < 1.6 * t_one, (t_two, t_one)
+    for o in (o1, o2, (oa, ob)):
+        assert torch.equal(o[0], ref_a) and torch.equal(o[1], ref_b)
+    bk.check(lwe_a)                                        # every input was an odd residue: status clean

@@ -95,6 +95,25 @@ def test_extend_rescale_vs_oracle(fhe, cref, torch_cuda, log_n):
             assert np.array_equal(out[b], cref.rns_rescale_k(qs + ps[:k], k, full[b])), (k, b)
 
 
+@pytest.mark.parametrize("bits,two_adicity,big_l,big_k", [(55, 10, 8, 8), (60, 16, 3, 5), (45, 17, 4, 2), (55, 12, 9, 3)])
+def test_switch_bases_vs_oracle(fhe, cref, torch_cuda, bits, two_adicity, big_l, big_k):
+    """util/src/ring/rns.rs:93-97 `switch_bases` in both directions through ONE context (the reference builds an `Rns` per call): the
+    new limbs of extend_bases(qs -> ps) and of extend_bases(ps -> qs), bit-equal to the oracle -- pseudo-Mersenne bases of 55 and 60
+    bits (the unreduced route, incl. more than eight source limbs) and primes that are not (the Shoup route)."""
+    n, batch = 64, 3
+    primes = cref.two_adic_primes(bits, two_adicity, big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    xq, xp = rand_limbs(bits, qs, n, batch), rand_limbs(bits + 1, ps, n, batch)
+    xq[0, :, 0] = [q - 1 for q in qs]  # extremes: every residue at its maximum / zero
+    xp[0, :, 1] = 0
+    to_p, to_q = host(rns.switch_bases(dev(torch_cuda, xq), n)), host(rns.switch_bases(dev(torch_cuda, xp), n, to_qs=True))
+    assert np.array_equal(to_p, host(rns.extend_bases(dev(torch_cuda, xq), n)))
+    for b in range(batch):
+        assert np.array_equal(to_p[b], cref.rns_extend_bases(qs, ps, xq[b])), b
+        assert np.array_equal(to_q[b], cref.rns_extend_bases(ps, qs, xp[b])), b
+
+
 @pytest.mark.parametrize("log_n,bits,big_l", [(4, 50, 3), (10, 55, 4), (13, 60, 2)])
 def test_ckks_key_switch_vs_oracle(fhe, cref, torch_cuda, log_n, bits, big_l):
     n, batch = 1 << log_n, 2

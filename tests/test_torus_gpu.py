@@ -372,3 +372,35 @@ def test_gate_bootstrap_decode_level_n1024(fhe, cref, torch_cuda):
         if li == 0:  # 4 of the 16 through the exact oracle's whole gate (n_lwe = 256 CMUXes each)
             ga, gb = cref.tfhe_bootstrap(log_b, d, 4, 5, ra, rb, ksa, ksb, v, a_raw[[0, 5, 10, 15]], b_raw[[0, 5, 10, 15]], threads=16)
             assert np.array_equal(hka[[0, 5, 10, 15]], ga) and np.array_equal(hkb[[0, 5, 10, 15]], gb)
+
+
+@pytest.mark.parametrize("log_n,log_b,d", [(8, 15, 2), (10, 7, 3), (11, 23, 1)])
+def test_cmux_and_rotate_entries(fhe, torch_cuda, log_n, log_b, d):
+    """Stand-alone entries of row T: `Tggsw::cmux(b, ct0, ct1)` = ct0 + external_product(b, ct1 - ct0) for ARBITRARY ct1
+    (scheme/tfhe/src/tggsw.rs:114-121; the blind rotation only ever needs ct1 = ct0 X^a) and `TglweCiphertext::rotate`
+    (tglwe.rs:61-66), bit-equal to the exact oracle on both prime paths; cmux(b, ct, ct.rotate(a)) is one step of the reference's
+    blind rotation (bootstrapping.rs:91-94)."""
+    from oracle import cref
+    n, batch = 1 << log_n, 3
+    rng = np.random.Generator(np.random.PCG64(log_n))
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)  # noqa: E731
+    ra, rb = r64(2, 2 * d, n), r64(2, 2 * d, n)
+    t = fhe.TorusContext()
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+    c0a, c0b, c1a, c1b = r64(batch, n), r64(batch, n), r64(batch, n), r64(batch, n)
+    oa, ob = key.cmux(1, dev(torch_cuda, c0a), dev(torch_cuda, c0b), dev(torch_cuda, c1a), dev(torch_cuda, c1b))
+    for i in range(batch):
+        ea, eb = cref.tggsw_external_product(log_b, d, ra[1], rb[1], c1a[i] - c0a[i], c1b[i] - c0b[i])
+        assert np.array_equal(host(oa)[i], c0a[i] + ea) and np.array_equal(host(ob)[i], c0b[i] + eb), i
+    for k in (0, 1, n - 1, n, n + 3, 2 * n - 1, -1, -n - 5, 7 * n + 2):
+        xa, xb = fhe.tglwe_rotate(dev(torch_cuda, c0a), dev(torch_cuda, c0b), n, k)
+        for i in range(batch):
+            assert np.array_equal(host(xa)[i], cref.torus_monomial_mul(c0a[i], k)) and np.array_equal(host(xb)[i], cref.torus_monomial_mul(c0b[i], k)), (k, i)
+    # one blind-rotation step through the two entries == the fused CMUX of the blind rotation kernel (rotation form)
+    a_t = 2 * n - 37
+    xa, xb = fhe.tglwe_rotate(dev(torch_cuda, c0a), dev(torch_cuda, c0b), n, a_t)
+    sa, sb = key.cmux(0, dev(torch_cuda, c0a), dev(torch_cuda, c0b), xa, xb)
+    for i in range(batch):
+        ra_, rb_ = cref.torus_monomial_mul(c0a[i], a_t), cref.torus_monomial_mul(c0b[i], a_t)
+        ea, eb = cref.tggsw_external_product(log_b, d, ra[0], rb[0], ra_ - c0a[i], rb_ - c0b[i])
+        assert np.array_equal(host(sa)[i], c0a[i] + ea) and np.array_equal(host(sb)[i], c0b[i] + eb)
