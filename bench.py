@@ -362,7 +362,7 @@ def sharded_secondary(torch, F, dist, dev, local_rank, rank, world, backend):
     """SURVEY.md 8(e) rows 2 and 3 under the multi-GPU launch: cfg3 / cfg5 ciphertext batches split across the ranks (keys
     replicated, no collective), cfg4 with the RNS limbs sharded (L = K = world: one all-gather of the p-limb products per key
     switch, timed apart).  Rates are whole-job: units of all ranks / max time over ranks."""
-    from learn_fhe_amd.shard import shard_range, GpuLimbOps, ckks_key_switch_limb_sharded, dist_all_gather
+    from learn_fhe_amd.shard import shard_range
 
     def job_rate(units_total, fn, reps):
         fn()
@@ -386,34 +386,33 @@ def sharded_secondary(torch, F, dist, dev, local_rank, rank, world, backend):
     # cfg5: BASELINE's 8192 ciphertexts over 8 GPUs = 1024 per GPU
     T = tfhe_setup(torch, F, dev, local_rank, 1024)
     out["tfhe_gate_bootstraps_per_sec"] = job_rate(1024 * world, lambda: T["key"].bootstrap(T["ks_lb"], T["ks_d"], T["ksa"], T["ksb"], T["v"], T["a_raw"], T["b_raw"]), 1)
-    # cfg4: limbs sharded, L = K = world
+    # cfg4: limbs sharded, L = K = world, a BATCH of 64 ciphertexts per call on the library's sharded entry points (fhe_ckks_shard_*):
+    # every rank holds the context and the key and owns q-limb `rank` and p-limb `rank`; ONE all-gather of the p-limb products
+    # per batch (RCCL on device memory under nccl, no host synchronisation around it)
     import ctypes as C
-    n = 1 << 15
+    from learn_fhe_amd.shard import limb_slices, ckks_key_switch_sharded_batch, all_gather_into
+    n, cbatch = 1 << 15, 64
     primes = (C.c_uint64 * (2 * world))()
     if F.lib().fhe_two_adic_primes(60, 16, 2 * world, primes) == 2 * world:
         qs, ps = list(primes)[:world], list(primes)[world:]
-        ops = GpuLimbOps(F, qs, ps, rank, device=local_rank)
+        rns = F.RnsContext(qs, ps, device=local_rank)
         gen = torch.Generator(device=dev)
-        gen.manual_seed(40)  # the same ciphertext on every rank (ct.a is replicated at staging)
-        ct_a_all = torch.stack([torch.randint(0, m, (n,), dtype=torch.int64, device=dev, generator=gen) for m in qs])
-        ct_b = torch.randint(0, qs[rank], (n,), dtype=torch.int64, device=dev, generator=gen)
-        keys = [ops.key_to_eval(w_, torch.randint(0, m, (n,), dtype=torch.int64, device=dev, generator=gen), n)
-                for w_, m in (("q", qs[rank]), ("q", qs[rank]), ("p", ps[rank]), ("p", ps[rank]))]
-        gather_s = [0.0]
-
-        def timed_gather(x):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            y = dist_all_gather(x)
-            torch.cuda.synchronize()
-            gather_s[0] += time.perf_counter() - t0
-            return y
-
-        ks = lambda: ckks_key_switch_limb_sharded(ops, rank, world, n, ct_b, ct_a_all, keys[0], keys[1], keys[2], keys[3], timed_gather)  # noqa: E731
-        reps = 5
-        out["ckks_limb_sharded_key_switches_per_sec"] = job_rate(1, ks, reps)
-        out["ckks_all_gather_ms_per_key_switch"] = gather_s[0] / (reps + 1) * 1e3
-        out["ckks_limbs"] = "L = K = %d (one q-limb and one p-limb per rank), N = 2^15" % world
+        gen.manual_seed(40)  # the same key and ciphertexts on every rank (ct.a is replicated at staging)
+        limbs = lambda ms, *lead: torch.stack([torch.randint(0, m, (*lead, n), dtype=torch.int64, device=dev, generator=gen) for m in ms], dim=len(lead)).contiguous()  # noqa: E731
+        key = F.CkksKey(rns, limbs(qs + ps), limbs(qs + ps), n)
+        q_lo, q_hi, p_lo, p_hi = limb_slices(world, world, rank, world)
+        shard = F.CkksShard(key, q_lo, q_hi, p_lo, p_hi)
+        ct_a_all, ct_b_all = limbs(qs, cbatch), limbs(qs, cbatch)
+        ct_b = ct_b_all[:, q_lo:q_hi].contiguous()
+        out["ckks_limb_sharded_key_switches_per_sec"] = job_rate(cbatch, lambda: ckks_key_switch_sharded_batch(shard, ct_b, ct_a_all), 5)
+        probe = torch.zeros((2, cbatch, p_hi - p_lo, n), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            all_gather_into(probe)
+        torch.cuda.synchronize()
+        out["ckks_all_gather_ms_per_batch"] = (time.perf_counter() - t0) / 5 * 1e3
+        out["ckks_limbs"] = "L = K = %d (one q-limb and one p-limb per rank), N = 2^15, batch %d per call" % (world, cbatch)
     return out
 
 

@@ -224,6 +224,28 @@ void fhe_ckks_key_destroy(fhe_ckks_key *key);
  * ciphertexts: ct_b, ct_a [batch][L][n] over qs, coefficient domain.  n up to 2^17. */
 int fhe_ckks_key_switch(const fhe_rns_ctx *rns, const fhe_ckks_key *key, uint64_t *ct_b, uint64_t *ct_a, size_t batch,
                         fhe_mem mem, void *stream);
+/* ---- the key switch with its RNS limbs sharded over devices -------------------------------
+ * `Ckks::key_switch` (scheme/ckks/src/ckks.rs:284-293) is limb-wise except for its two base conversions.  Every device holds the
+ * context and the prepared key (replicated: 8 MiB at cfg4) and OWNS the q-limbs [q_lo, q_hi) and the p-limbs [p_lo, p_hi); all devices
+ * own equally many p-limbs (np divides K).  Per batch of ciphertexts:
+ *   1. fhe_ckks_shard_products  local: ct.a (all L q-limbs, replicated at staging) -> the two key products on the owned limbs;
+ *   2. the caller ALL-GATHERS prod_p over the devices -- the one exchange of the path: an RCCL all-gather in the caller's own
+ *      communicator, or hipMemcpyPeerAsync into each peer's gather buffer (examples/multi_gpu_ckks_demo.c); contribution of the
+ *      device that owns p-limbs [p_lo, p_hi) goes to slot p_lo / np;
+ *   3. fhe_ckks_shard_finish    local: rescale_k on the owned q-limbs against all K gathered p-limbs (+ ct.b's owned limbs).
+ * The library links neither RCCL nor peer copies: step 2 sits between two calls, where the caller's communicator already lives.
+ * Bases of pseudo-Mersenne primes of one bit length only (every CkksParam of the reference): FHE_ERR_UNSUPPORTED otherwise. */
+typedef struct fhe_ckks_shard fhe_ckks_shard;
+int fhe_ckks_shard_create(const fhe_rns_ctx *rns, const fhe_ckks_key *key, int q_lo, int q_hi, int p_lo, int p_hi, fhe_ckks_shard **out);
+void fhe_ckks_shard_destroy(fhe_ckks_shard *shard);
+/* ct_a [batch][L][n] -> prod_q [2][batch][nq][n], prod_p [2][batch][np][n] (part 0: ksk.b * a~, part 1: ksk.a * a~; an internal
+ * coefficient-domain form that only fhe_ckks_shard_finish reads) */
+int fhe_ckks_shard_products(const fhe_ckks_shard *shard, const uint64_t *ct_a, uint64_t *prod_q, uint64_t *prod_p, size_t batch, fhe_mem mem,
+                            void *stream);
+/* prod_q (stage 1), gathered_p [K / np][2][batch][np][n], ct_b [batch][nq][n] (ct.b's owned limbs, or NULL) -> out_b, out_a
+ * [batch][nq][n]: the owned limbs of the switched ciphertext, bit-identical to fhe_ckks_key_switch's */
+int fhe_ckks_shard_finish(const fhe_ckks_shard *shard, const uint64_t *prod_q, const uint64_t *gathered_p, const uint64_t *ct_b,
+                          uint64_t *out_b, uint64_t *out_a, size_t batch, fhe_mem mem, void *stream);
 /* util/src/ring/rns.rs:99-101 `RnsRq::rescale()` = rescale_k(1) over qs alone: drops the last q-limb (the K == 1 branch of
  * rns.rs:104-111, NOT centred).  in [batch][L][n] -> out [batch][L-1][n]; L >= 2. */
 int fhe_rns_rescale(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream);

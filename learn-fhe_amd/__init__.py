@@ -5,7 +5,7 @@ sources in `csrc/`.  This Python package is only the harness-side binding used b
 it loads the library with ctypes and fails loudly if it is missing -- there is no CPU fallback.
 """
 from ._lib import FheError, build, lib, lib_path, set_option  # noqa: F401
-from .ring import (BootstrapKey, CkksKey, Fhew, GadgetKey, NttContext, RnsContext, TggswKey, TorusContext,  # noqa: F401
+from .ring import (BootstrapKey, CkksKey, CkksShard, Fhew, GadgetKey, NttContext, RnsContext, TggswKey, TorusContext,  # noqa: F401
                    ak_t, automorphism, decompose, lwe_key_switch, lwe_lincomb, lwe_mod_switch, monomial_mul, rlwe_sample_extract, rq_add, rq_from_i64, rq_neg, rq_scalar_mul, rq_sub,
                    tglwe_sample_extract, tlwe_key_switch, torus_decompose, tglwe_rotate,
                    power_up, rgsw_encrypt, rlwe_ksk_gen, rlwe_sk_encrypt, sample_dg, sample_torus, sample_uniform,

@@ -96,6 +96,11 @@ def lib():
         L.fhe_ckks_key_destroy.argtypes = [vp]
         L.fhe_ckks_key_destroy.restype = None
         L.fhe_ckks_key_switch.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_ckks_shard_create.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(vp)]
+        L.fhe_ckks_shard_destroy.argtypes = [vp]
+        L.fhe_ckks_shard_destroy.restype = None
+        L.fhe_ckks_shard_products.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_ckks_shard_finish.argtypes = [vp, vp, vp, vp, vp, vp, sz, ci, vp]
         L.fhe_lwe_mod_switch.argtypes = [C.c_uint64, C.c_uint64, vp, vp, sz, ci, ci, vp]
         L.fhe_rq_add.argtypes = [C.c_uint64, vp, vp, vp, sz, ci, vp]
         L.fhe_rq_sub.argtypes = [C.c_uint64, vp, vp, vp, sz, ci, vp]

@@ -88,6 +88,11 @@ struct NttIo {
     // 128 workgroups -- half a chip each for the one-workgroup-per-CU kernels.
     const u64 *src2 = nullptr, *src3 = nullptr, *src4 = nullptr;
     unsigned src_group = 0;
+    // (multiplying inverse of the wave-local kernels only) split output: with dst_period = P and dst_first2 = F, polynomial s = g P + l
+    // is STORED at data + (g F + l) polynomials if l < F, at dst2 + (g (P - F) + l - F) polynomials otherwise -- a limb-sharded key
+    // switch gets its q-limb products and its p-limb products (the ones the all-gather sends) as two contiguous blocks
+    u64 *dst2 = nullptr;
+    unsigned dst_period = 0, dst_first2 = 0;
 };
 // where sub-polynomial `sub` (2^log_len words) is read from; `own` = its place in the launch's buffer
 __device__ __forceinline__ const u64 *ntt_src(const NttIo &io, unsigned sub, int log_len, const u64 *own) {

@@ -682,6 +682,14 @@ __global__ __launch_bounds__(w14::threads<R0>(), 4) void ntt14w_inv_kernel(u64 *
     const ModDesc &D = descs[n_desc == 1 ? 0 : poly % n_desc];
     const typename A::K k = A::make(D, LOG_N, PFX ? pb : 0, PFX ? int(sub & ((1u << pb) - 1)) : 0);
     u64 *g = data + (size_t(sub) << LOG_N);
+    if constexpr (MUL) {
+        if (io.dst2) {  // split output (NttIo::dst2): the launch's source is io.src, `g` is only where this workgroup stores
+            const unsigned grp = poly / io.dst_period, l = poly - grp * io.dst_period, part = PFX ? sub & ((1u << pb) - 1) : 0;
+            const unsigned pbs = PFX ? pb : 0;
+            g = l < io.dst_first2 ? data + (((size_t(grp) * io.dst_first2 + l) << pbs | part) << LOG_N)
+                                  : io.dst2 + (((size_t(grp) * (io.dst_period - io.dst_first2) + (l - io.dst_first2)) << pbs | part) << LOG_N);
+        }
+    }
     u64 x[32];
     w14::Tw7<A> d[2];
     auto load_first_twiddles = [&]() {

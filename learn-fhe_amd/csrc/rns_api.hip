@@ -38,6 +38,15 @@ struct fhe_ckks_key {
     u64 *d_kb = nullptr, *d_ka = nullptr;  // [L + K][n], evaluation domain
 };
 
+// one device's part of a limb-sharded key switch (include/fhe_ring.h: fhe_ckks_shard_create)
+struct fhe_ckks_shard {
+    const fhe_rns_ctx *rns = nullptr;
+    int log_n = 0, q_lo = 0, q_hi = 0, p_lo = 0, p_hi = 0;
+    bool edge = false;                 // N = 2^15: the transforms' outermost layer runs inside the extend / rescale kernels
+    fhe::ModDesc *d_descs = nullptr;   // [nq + np]: the owned q-limbs, then the owned p-limbs
+    u64 *d_key = nullptr;              // [2][nq + np][n]: ksk.b then ksk.a on the owned limbs, evaluation domain
+};
+
 namespace {
 
 using fhe::mulmod;
@@ -369,54 +378,74 @@ struct PointwiseGrid {
         g = dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(polys > 65535 ? 65535 : polys));
     }
 };
+// rows [lo, ..) of a table of output rows (a limb-sharded key switch computes only the limbs it owns)
+fhe::PmRows rows_from(const fhe::PmRows &R, int lo) { return fhe::PmRows{R.stride, R.tab + size_t(lo) * (3 * R.stride + fhe::PM_ROW_TAIL)}; }
+
 // the new limbs of extend_bases: qs -> ps (in [batch][L][n] -> out [batch][K][n]) or, `to_qs`, ps -> qs; `copy` (optional) receives the
-// source limbs
+// source limbs [c_lo, c_hi); only the target rows [r_lo, r_hi) are produced (default: all)
 void launch_extend(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st,
-                   u64 *copy = nullptr, size_t copy_bs = 0, bool to_qs = false) {
+                   u64 *copy = nullptr, size_t copy_bs = 0, bool to_qs = false, int c_lo = 0, int c_hi = -1, int r_lo = 0, int r_hi = -1) {
     const dim3 grid(grid_for(n * batch));
     const int la = to_qs ? r->K : r->L, lb = to_qs ? r->L : r->K;
+    if (c_hi < 0) c_hi = la;
+    if (r_hi < 0) r_hi = lb;
     if (r->pm) {
         const fhe::PmSrc &S = to_qs ? r->s_p2q_plain : r->s_q2p;
-        const fhe::PmRows &R = to_qs ? r->r_p2q_plain : r->r_q2p;
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, S, R, lb, r->uni, copy, copy_bs)
+        const fhe::PmRows R = rows_from(to_qs ? r->r_p2q_plain : r->r_q2p, r_lo);
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, S, R, r_hi - r_lo, r->uni, copy, copy_bs, c_lo, c_hi)
         RNS_BOUND(la, CALL);
 #undef CALL
-    } else {
+    } else {  // (the Shoup route has no limb subsets: callers check r->pm first)
         const fhe::BaseConv &C = to_qs ? r->p2q : r->q2p;
 #define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, C, copy, copy_bs)
         RNS_BOUND(la, CALL);
 #undef CALL
     }
 }
-// rescale_k(K) (last = false: in [batch][L+K][n] -> out [batch][L][n]) or rescale() (last = true: in [batch][L][n] -> [batch][L-1][n])
-void launch_rescale(const fhe_rns_ctx *r, bool last, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
-                    size_t batch, hipStream_t st) {
+// where a whole [batch][L+K][n] block keeps the limbs of a rescale (rns_kernels.hpp RescaleIn)
+fhe::RescaleIn rescale_in_block(const u64 *in, size_t in_bs, int L, int K, size_t n) {
+    fhe::RescaleIn I{};
+    I.in_q = in; I.q_bs = in_bs; I.in_p = in + size_t(L) * n; I.p_bs = in_bs;
+    for (int j = 0; j < K; ++j) I.off[j] = size_t(j) * n;
+    return I;
+}
+// rescale_k(K) (last = false: L q-limbs + K p-limbs -> out [batch][L][n]) or rescale() (last = true: in [batch][L][n] -> [batch][L-1][n]);
+// rows [q_lo, q_hi) of the q-limbs only (pseudo-Mersenne route; default: all), I.in_q then holds those limbs
+void launch_rescale(const fhe_rns_ctx *r, bool last, const fhe::RescaleIn &I, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
+                    size_t batch, hipStream_t st, int q_lo = 0, int q_hi = -1) {
     const dim3 grid(grid_for(n * batch));
     const int k = last ? 1 : r->K, L = last ? r->L - 1 : r->L;
+    if (q_hi < 0) q_hi = L;
     if (r->pm) {
         const fhe::PmSrc &S = last ? r->s_last : r->s_p2q;
-        const fhe::PmRows &R = last ? r->r_last : r->r_resc;
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_pm_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, L, S, R, r->uni)
+        const fhe::PmRows R = rows_from(last ? r->r_last : r->r_resc, q_lo);
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_pm_kernel<M, F>), grid, dim3(256), 0, st, I, out, out_bs, addend, add_bs, n, batch, q_hi - q_lo, S, R, r->uni)
         RNS_BOUND(k, CALL);
 #undef CALL
     } else {
         const fhe::RescaleConsts &R = last ? r->resc_last : r->resc;
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F>), grid, dim3(256), 0, st, in, in_bs, out, out_bs, addend, add_bs, n, batch, R)
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_kernel<M, F>), grid, dim3(256), 0, st, I.in_q, I.q_bs, out, out_bs, addend, add_bs, n, batch, R)
         RNS_BOUND(k, CALL);
 #undef CALL
     }
 }
 // the same two steps with the outermost transform layer of a 2^15 ring in them (rns_kernels.hpp); pseudo-Mersenne bases only
-void launch_extend_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st) {
+void launch_extend_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, size_t n, size_t batch, hipStream_t st,
+                        int c_lo = 0, int c_hi = -1, int r_lo = 0, int r_hi = -1) {
+    if (c_hi < 0) c_hi = r->L;
+    if (r_hi < 0) r_hi = r->K;
+    const fhe::PmRows R = rows_from(r->r_q2p, r_lo), RW = rows_from(r->r_q2p_w, r_lo);
 #define CALL(M, F) hipLaunchKernelGGL((fhe::rns_extend_edge_pm_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, n, batch, \
-                                      r->s_q2p, r->r_q2p, r->r_q2p_w, r->K, r->uni)
+                                      r->s_q2p, R, RW, r_hi - r_lo, r->uni, c_lo, c_hi)
     RNS_BOUND(r->L, CALL);
 #undef CALL
 }
-void launch_rescale_edge(const fhe_rns_ctx *r, const u64 *in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
-                         size_t batch, hipStream_t st) {
-#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_pm_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, in, in_bs, out, out_bs, addend, \
-                                      add_bs, n, batch, r->L, r->s_p2q_sum, r->s_p2q_diff, r->r_resc_edge, r->uni)
+void launch_rescale_edge(const fhe_rns_ctx *r, const fhe::RescaleIn &I, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs, size_t n,
+                         size_t batch, hipStream_t st, int q_lo = 0, int q_hi = -1) {
+    if (q_hi < 0) q_hi = r->L;
+    const fhe::PmRows R = rows_from(r->r_resc_edge, q_lo);
+#define CALL(M, F) hipLaunchKernelGGL((fhe::rns_rescale_edge_pm_kernel<M, F>), dim3(grid_for(n / 2 * batch)), dim3(256), 0, st, I, out, out_bs, addend, \
+                                      add_bs, n, batch, q_hi - q_lo, r->s_p2q_sum, r->s_p2q_diff, R, r->uni)
     RNS_BOUND(r->K, CALL);
 #undef CALL
 }
@@ -465,7 +494,7 @@ int fhe_rns_rescale_k(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, s
     const size_t lk = size_t(r->L + r->K);
     Mirror mi(in, n * batch * lk, mem, true, st), mo(out, n * batch * r->L, mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(r, false, mi.d, lk * n, mo.d, size_t(r->L) * n, nullptr, 0, n, batch, st);
+    launch_rescale(r, false, rescale_in_block(mi.d, lk * n, r->L, r->K, n), mo.d, size_t(r->L) * n, nullptr, 0, n, batch, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -581,8 +610,8 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
             rc = fhe::ntt_inv_inner15(r->d_descs, (unsigned)lk, pb, 2 * batch * lk, st, r->all_pm, io);
         }
         if (rc == FHE_OK) {
-            launch_rescale_edge(r, pb, lk * n, out_b, L * n, add_b, L * n, n, batch, st);
-            launch_rescale_edge(r, pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, st);
+            launch_rescale_edge(r, rescale_in_block(pb, lk * n, r->L, r->K, n), out_b, L * n, add_b, L * n, n, batch, st);
+            launch_rescale_edge(r, rescale_in_block(pb + blk, lk * n, r->L, r->K, n), out_a, L * n, add_a, L * n, n, batch, st);
             if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
         }
         return rc;
@@ -604,8 +633,8 @@ int key_switch_dev(const fhe_rns_ctx *r, const fhe_ckks_key *key, const u64 *a_i
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) {
-        launch_rescale(r, false, pb, lk * n, out_b, L * n, add_b, L * n, n, batch, st);
-        launch_rescale(r, false, pb + blk, lk * n, out_a, L * n, add_a, L * n, n, batch, st);
+        launch_rescale(r, false, rescale_in_block(pb, lk * n, r->L, r->K, n), out_b, L * n, add_b, L * n, n, batch, st);
+        launch_rescale(r, false, rescale_in_block(pb + blk, lk * n, r->L, r->K, n), out_a, L * n, add_a, L * n, n, batch, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     return rc;
@@ -630,6 +659,137 @@ int fhe_ckks_key_switch(const fhe_rns_ctx *r, const fhe_ckks_key *key, uint64_t 
     return rc;
 }
 
+// ---- the key switch with its RNS limbs sharded over devices ------------------------------------
+// `Ckks::key_switch` (scheme/ckks/src/ckks.rs:284-293) is limb-wise except for its two base conversions.  A device that owns the
+// q-limbs [q_lo, q_hi) and the p-limbs [p_lo, p_hi):
+//   stage 1  extends the replicated ct.a to ITS p-limbs (every source limb is needed for that, only the owned rows are computed),
+//            transforms its nq + np limbs, multiplies by its key limbs on the inverse's load -- the same fused kernels as the
+//            single-device key switch, over nl = nq + np limbs instead of L + K -- and leaves the q-limb products and the
+//            p-limb products in two contiguous blocks (NttIo::dst2);
+//   (the caller all-gathers the p-limb blocks: the ONE exchange of the path)
+//   stage 2  rescales its q-limbs against all K gathered p-limbs (+ ct.b's owned limbs).
+// All arithmetic is the single-device path's, so the outputs are the same bits (tests/test_rns_gpu.py).
+void fhe_ckks_shard_destroy(fhe_ckks_shard *sh) {
+    if (!sh) return;
+    if (sh->rns && sh->rns->device >= 0) {
+        DeviceGuard guard(sh->rns->device);
+        if (sh->d_descs) (void)hipFree(sh->d_descs);
+        if (sh->d_key) (void)hipFree(sh->d_key);
+    }
+    delete sh;
+}
+
+int fhe_ckks_shard_create(const fhe_rns_ctx *r, const fhe_ckks_key *key, int q_lo, int q_hi, int p_lo, int p_hi, fhe_ckks_shard **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!r || !key || key->rns != r || q_lo < 0 || q_hi <= q_lo || q_hi > r->L || p_lo < 0 || p_hi <= p_lo || p_hi > r->K) return FHE_ERR_INVALID;
+    if (r->K % (p_hi - p_lo)) return FHE_ERR_INVALID;  // the gathered p-limbs come as K / np equal contributions
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (!r->pm) return FHE_ERR_UNSUPPORTED;  // limb subsets exist on the pseudo-Mersenne route only (every CkksParam of the reference)
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    fhe_ckks_shard *sh = new (std::nothrow) fhe_ckks_shard();
+    if (!sh) return FHE_ERR_INVALID;
+    sh->rns = r; sh->log_n = key->log_n; sh->q_lo = q_lo; sh->q_hi = q_hi; sh->p_lo = p_lo; sh->p_hi = p_hi;
+    sh->edge = key->log_n == 15 && r->L <= 8 && r->K <= 8;
+    const int nq = q_hi - q_lo, np = p_hi - p_lo, nl = nq + np;
+    const size_t n = size_t(1) << key->log_n;
+    std::vector<fhe::ModDesc> descs(nl);
+    for (int i = 0; i < nl; ++i) descs[i] = r->mods[i < nq ? q_lo + i : r->L + p_lo + (i - nq)]->h_desc;
+    hipError_t e = hipMalloc((void **)&sh->d_descs, nl * sizeof(fhe::ModDesc));
+    if (e == hipSuccess) e = hipMemcpy(sh->d_descs, descs.data(), nl * sizeof(fhe::ModDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&sh->d_key, 2 * size_t(nl) * n * sizeof(u64));
+    for (int part = 0; part < 2 && e == hipSuccess; ++part) {
+        const u64 *full = part ? key->d_ka : key->d_kb;
+        u64 *dst = sh->d_key + size_t(part) * nl * n;
+        e = hipMemcpy(dst, full + size_t(q_lo) * n, size_t(nq) * n * sizeof(u64), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dst + size_t(nq) * n, full + size_t(r->L + p_lo) * n, size_t(np) * n * sizeof(u64), hipMemcpyDeviceToDevice);
+    }
+    if (e != hipSuccess) { g_last_hip = (int)e; fhe_ckks_shard_destroy(sh); return FHE_ERR_HIP; }
+    *out = sh;
+    return FHE_OK;
+}
+
+// stage 1: ct_a [batch][L][n] (ALL q-limbs: replicated) -> prod_q [2][batch][nq][n], prod_p [2][batch][np][n]: ksk.b * a~ (part 0) and
+// ksk.a * a~ (part 1) on the owned limbs, coefficient domain (at N = 2^15 short of the inverse transforms' outermost layer and of
+// n^-1, which stage 2 applies: an internal form, only fhe_ckks_shard_finish reads it)
+int fhe_ckks_shard_products(const fhe_ckks_shard *sh, const uint64_t *ct_a, uint64_t *prod_q, uint64_t *prod_p, size_t batch, fhe_mem mem,
+                            void *stream) {
+    if (!sh || ((!ct_a || !prod_q || !prod_p) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const fhe_rns_ctx *r = sh->rns;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int nq = sh->q_hi - sh->q_lo, np = sh->p_hi - sh->p_lo, nl = nq + np, log_n = sh->log_n;
+    const size_t n = size_t(1) << log_n, L = r->L;
+    if ((2 * batch * nl) >> 30) return FHE_ERR_UNSUPPORTED;
+    Mirror ma(ct_a, batch * L * n, mem, true, st), mq(prod_q, 2 * batch * nq * n, mem, false, st), mp(prod_p, 2 * batch * np * n, mem, false, st);
+    if (ma.rc | mq.rc | mp.rc) return FHE_ERR_HIP;
+    // the split store of the multiplying inverse exists in the wave-local kernels (2^12 .. 2^15); other ring sizes pack afterwards
+    const bool split = log_n >= 14 && log_n <= 15 ? true : ((log_n == 12 || log_n == 13) && fhe::opt(fhe::OPT_NO_W12) == 0);
+    StreamWs wsp((batch * nl * n + (split ? 0 : 2 * batch * nl * n)) * sizeof(u64), st);  // ext [batch][nl][n] (| prod [2][batch][nl][n])
+    if (wsp.rc != FHE_OK) return wsp.rc;
+    u64 *ext = wsp.as<u64>(), *tmp = ext + batch * nl * n;
+    int rc = FHE_OK;
+    if (sh->edge) launch_extend_edge(r, ma.d, L * n, ext, size_t(nl) * n, n, batch, st, sh->q_lo, sh->q_hi, sh->p_lo, sh->p_hi);
+    else launch_extend(r, ma.d, L * n, ext + size_t(nq) * n, size_t(nl) * n, n, batch, st, ext, size_t(nl) * n, false, sh->q_lo, sh->q_hi, sh->p_lo, sh->p_hi);
+    if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    if (rc == FHE_OK && n > 1)
+        rc = sh->edge ? fhe::ntt_fwd_inner15(sh->d_descs, (unsigned)nl, ext, batch * nl, st, r->all_pm)
+                      : fhe::ntt_fwd_multi(sh->d_descs, (unsigned)nl, ext, log_n, batch * nl, st, r->all_pm);
+    if (rc == FHE_OK && n > 1) {
+        fhe::NttIo io;
+        io.src = ext; io.src_mod = (unsigned)(batch * nl);
+        io.mul = sh->d_key; io.mul_div = (unsigned)(batch * nl); io.mul_period = (unsigned)nl;
+        if (split) { io.dst2 = mp.d; io.dst_period = (unsigned)nl; io.dst_first2 = (unsigned)nq; }
+        u64 *dst = split ? mq.d : tmp;
+        rc = sh->edge ? fhe::ntt_inv_inner15(sh->d_descs, (unsigned)nl, dst, 2 * batch * nl, st, r->all_pm, io)
+                      : fhe::ntt_inv_multi(sh->d_descs, (unsigned)nl, dst, log_n, 2 * batch * nl, st, r->all_pm, io);
+    } else if (rc == FHE_OK) {  // n = 1: the ring product is the scalar product
+        hipLaunchKernelGGL(fhe::rns_pointwise2_desc_kernel, PointwiseGrid(n, batch * nl).g, dim3(256), 0, st, (const u64 *)ext, (const u64 *)sh->d_key,
+                           (const u64 *)(sh->d_key + size_t(nl) * n), tmp, tmp + batch * nl * n, (unsigned)n, (unsigned)nl, batch * nl, (const fhe::ModDesc *)sh->d_descs);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK && !split) {
+        hipLaunchKernelGGL(fhe::rns_split_limbs_kernel, dim3(grid_for(2 * batch * nl * n)), dim3(256), 0, st, (const u64 *)tmp, mq.d, mp.d, n, 2 * batch, nl, nq);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = mq.sync_out(st);
+    if (rc == FHE_OK) rc = mp.sync_out(st);
+    return rc;
+}
+
+// stage 2: prod_q [2][batch][nq][n] (stage 1), gathered_p [K / np][2][batch][np][n] (every device's prod_p, in p-limb order), ct_b
+// [batch][nq][n] (ct.b's owned limbs, or NULL) -> out_b, out_a [batch][nq][n]: the owned limbs of the switched ciphertext
+int fhe_ckks_shard_finish(const fhe_ckks_shard *sh, const uint64_t *prod_q, const uint64_t *gathered_p, const uint64_t *ct_b, uint64_t *out_b,
+                          uint64_t *out_a, size_t batch, fhe_mem mem, void *stream) {
+    if (!sh || ((!prod_q || !gathered_p || !out_b || !out_a) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    const fhe_rns_ctx *r = sh->rns;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int nq = sh->q_hi - sh->q_lo, np = sh->p_hi - sh->p_lo, K = r->K;
+    const size_t n = size_t(1) << sh->log_n, qw = batch * nq * n, pw = batch * np * n;
+    Mirror mq(prod_q, 2 * qw, mem, true, st), mg(gathered_p, size_t(K / np) * 2 * pw, mem, true, st), mb(ct_b, ct_b ? qw : 0, mem, true, st);
+    Mirror mob(out_b, qw, mem, false, st), moa(out_a, qw, mem, false, st);
+    if (mq.rc | mg.rc | mb.rc | mob.rc | moa.rc) return FHE_ERR_HIP;
+    for (int part = 0; part < 2; ++part) {
+        fhe::RescaleIn I{};
+        I.in_q = mq.d + size_t(part) * qw; I.q_bs = size_t(nq) * n;
+        I.in_p = mg.d + size_t(part) * pw; I.p_bs = size_t(np) * n;
+        for (int j = 0; j < K; ++j) I.off[j] = size_t(j / np) * 2 * pw + size_t(j % np) * n;
+        u64 *o = part ? moa.d : mob.d;
+        const u64 *add = part ? nullptr : (ct_b ? mb.d : nullptr);
+        if (sh->edge) launch_rescale_edge(r, I, o, size_t(nq) * n, add, size_t(nq) * n, n, batch, st, sh->q_lo, sh->q_hi);
+        else launch_rescale(r, false, I, o, size_t(nq) * n, add, size_t(nq) * n, n, batch, st, sh->q_lo, sh->q_hi);
+    }
+    HIP_TRY(hipGetLastError());
+    int rc = mob.sync_out(st);
+    return rc != FHE_OK ? rc : moa.sync_out(st);
+}
+
 // util/src/ring/rns.rs:99-101 `RnsRq::rescale()` = rescale_k(1): in [batch][L][n] -> out [batch][L-1][n]
 int fhe_rns_rescale(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream) {
     if (!r || ((!in || !out) && n * batch)) return FHE_ERR_INVALID;
@@ -642,7 +802,7 @@ int fhe_rns_rescale(const fhe_rns_ctx *r, const uint64_t *in, uint64_t *out, siz
     const size_t L = r->L;
     Mirror mi(in, n * batch * L, mem, true, st), mo(out, n * batch * (L - 1), mem, false, st);
     if (mi.rc | mo.rc) return FHE_ERR_HIP;
-    launch_rescale(r, true, mi.d, L * n, mo.d, (L - 1) * n, nullptr, 0, n, batch, st);
+    launch_rescale(r, true, rescale_in_block(mi.d, L * n, r->L - 1, 1, n), mo.d, (L - 1) * n, nullptr, 0, n, batch, st);
     HIP_TRY(hipGetLastError());
     return mo.sync_out(st);
 }
@@ -743,8 +903,8 @@ int fhe_ckks_mul(const fhe_rns_ctx *r, const fhe_ckks_key *rlk, const uint64_t *
     // (d0, d1) + relinearize(d2) (ckks.rs:262, 265-272): the key switch adds d0 and d1 as it rescales; its outputs reuse e
     if (rc == FHE_OK) rc = key_switch_dev(r, rlk, d + 2 * words, d, d + words, e, e + words, batch, st);
     if (rc == FHE_OK) {
-        launch_rescale(r, true, e, L * n, mob.d, (L - 1) * n, nullptr, 0, n, batch, st);
-        launch_rescale(r, true, e + words, L * n, moa.d, (L - 1) * n, nullptr, 0, n, batch, st);
+        launch_rescale(r, true, rescale_in_block(e, L * n, r->L - 1, 1, n), mob.d, (L - 1) * n, nullptr, 0, n, batch, st);
+        launch_rescale(r, true, rescale_in_block(e + words, L * n, r->L - 1, 1, n), moa.d, (L - 1) * n, nullptr, 0, n, batch, st);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     if (rc == FHE_OK) rc = mob.sync_out(st);

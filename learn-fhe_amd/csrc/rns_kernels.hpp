@@ -252,7 +252,7 @@ __device__ __forceinline__ u64 pm_row(const PmRows &R, int j, const PmRowK &k, c
 // util/src/ring/rns.rs:83-91: in [batch][la][n] (batch stride in_bs words) -> out [batch][rows][n] (stride out_bs)
 template <int MAXA, bool FULL>
 __global__ void rns_extend_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
-                                     PmSrc S, PmRows R, int rows, pd::Uni U, u64 *__restrict__ copy, size_t copy_bs) {
+                                     PmSrc S, PmRows R, int rows, pd::Uni U, u64 *__restrict__ copy, size_t copy_bs, int c_lo, int c_hi) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
@@ -262,7 +262,8 @@ __global__ void rns_extend_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u
         for (int l = 0; l < MAXA; ++l) {
             if (FULL || l < S.la) {
                 const u64 v = in[p * in_bs + size_t(l) * n + i];
-                if (copy) copy[p * copy_bs + size_t(l) * n + i] = v;  // the key switch wants the source limbs next to the new ones
+                // the key switch wants the source limbs next to the new ones (a limb-sharded one: the limbs [c_lo, c_hi) it owns)
+                if (copy && l >= c_lo && l < c_hi) copy[p * copy_bs + size_t(l - c_lo) * n + i] = v;
                 const pd::Y3 y = pm_src_one<false>(S.rec + l * PM_SRC_DW, v, acc, U);
                 y0[l] = y.y0; y1[l] = y.y1; yk[l] = y.yk;
                 FHE_SCHED_FENCE();  // one limb's record (16 scalar registers) at a time
@@ -280,22 +281,33 @@ __global__ void rns_extend_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u
     }
 }
 
-// util/src/ring/rns.rs:103-118 `rescale_k(K)`: in [batch][L+K][n] -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
+// where the limbs of a rescale's input live.  The whole key switch keeps them in one [batch][L+K][n] block; a limb-sharded one reads
+// its own q-limbs from one buffer and the K p-limbs from the all-gathered contributions of the other devices: p-limb j of
+// ciphertext c sits at in_p + off[j] + c * p_bs (off[j] set by the host: contribution j / np, local limb j % np)
+struct RescaleIn {
+    const u64 *in_q;  // [batch][L][n] (stride q_bs): the q-limbs this launch rescales
+    size_t q_bs;
+    const u64 *in_p;
+    size_t p_bs;
+    size_t off[RNS_MAX_LIMBS];
+};
+
+// util/src/ring/rns.rs:103-118 `rescale_k(K)`: L q-limbs + K p-limbs (RescaleIn) -> out [batch][L][n] (+ addend [batch][L][n] if non-null)
 // `out` may alias `addend` (each thread reads its addend element before it writes the same slot).  S: the p-limbs' side with
 // hk = half_j inv_j; R: one row per q-limb.  K == 1 is the reference's shortcut (rns.rs:108-111): no correction term u.
 template <int MAXA, bool FULL>
-__global__ void rns_rescale_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
+__global__ void rns_rescale_pm_kernel(RescaleIn I, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
                                       size_t n, size_t batch, int L, PmSrc S, PmRows R, pd::Uni U) {
     const size_t total = n * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / n, i = idx - p * n;
-        const u64 *src = in + p * in_bs + i, *ad = addend ? addend + p * add_bs + i : nullptr;
+        const u64 *src = I.in_q + p * I.q_bs + i, *psrc = I.in_p + p * I.p_bs + i, *ad = addend ? addend + p * add_bs + i : nullptr;
         u64 *dst = out + p * out_bs + i;
         unsigned y0[MAXA], y1[MAXA], yk[MAXA];
         double acc = 0.0;
         u64 vp[MAXA];
 #pragma unroll
-        for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < S.la) ? src[size_t(L + j) * n] : 0;  // every load in flight before the first product
+        for (int j = 0; j < MAXA; ++j) vp[j] = (FULL || j < S.la) ? psrc[I.off[j]] : 0;  // every load in flight before the first product
         u64 nx = src[0], na = ad ? ad[0] : 0;  // q-limb 0 flies under the p-limbs' work
 #pragma unroll
         for (int j = 0; j < MAXA; ++j) {
@@ -333,12 +345,13 @@ __global__ void rns_rescale_pm_kernel(const u64 *__restrict__ in, size_t in_bs, 
 // what is left of every transform is two INDEPENDENT 2^14 sub-transforms (ntt14w PFX form, pb = 1).  All arithmetic is exact mod
 // q_l, so the coefficient-domain results are bit-identical.  Pseudo-Mersenne bases only.
 
-// extend_bases + layer 0 of the forward transform of all la + rows limbs: in [batch][la][n] -> out [batch][la + rows][n].
+// extend_bases + layer 0 of the forward transform of the source limbs [c_lo, c_hi) and of `rows` new limbs:
+// in [batch][la][n] -> out [batch][c_hi - c_lo + rows][n] (the whole key switch: c_lo = 0, c_hi = la).
 // RW = R with every constant multiplied by the target modulus' tw[1]: the butterfly (X, Y) <- (X + w Y, X - w Y) (fft.rs:96-101)
 // of an output limb takes w Y straight from the second dot product; the source limbs' own butterflies take tw[1] from their record.
 template <int MAXA, bool FULL>
 __global__ void rns_extend_edge_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *__restrict__ out, size_t out_bs, size_t n, size_t batch,
-                                          PmSrc S, PmRows R, PmRows RW, int rows, pd::Uni U) {
+                                          PmSrc S, PmRows R, PmRows RW, int rows, pd::Uni U, int c_lo, int c_hi) {
     const size_t h = n >> 1, total = h * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / h, i = idx - p * h;
@@ -364,15 +377,17 @@ __global__ void rns_extend_edge_pm_kernel(const u64 *__restrict__ in, size_t in_
                 const u64 a = (u64)ldc(rec, 0) | ((u64)ldc(rec, 1) << 32);
                 const unsigned c = ldc(rec, 2);
                 const u64 t = csub(pd::fold(pd::ds_mul_raw(v1, ldc(rec, 12), ldc(rec, 13), ldc(rec, 14), ldc(rec, 15), 2 * c, U), c, U), a);
-                dst[size_t(l) * n] = csub(v0 + t, a);
-                dst[size_t(l) * n + h] = v0 >= t ? v0 - t : v0 + a - t;
+                if (l >= c_lo && l < c_hi) {  // (a limb-sharded key switch keeps only the source limbs it owns)
+                    dst[size_t(l - c_lo) * n] = csub(v0 + t, a);
+                    dst[size_t(l - c_lo) * n + h] = v0 >= t ? v0 - t : v0 + a - t;
+                }
                 FHE_SCHED_FENCE();
             } else {
                 a0[l] = a1[l] = ak[l] = b0[l] = b1[l] = bk[l] = 0;
             }
         }
         const unsigned u0 = (unsigned)(int)round(acc0), u1 = (unsigned)(int)round(acc1);
-        u64 *dp = dst + size_t(S.la) * n;
+        u64 *dp = dst + size_t(c_hi - c_lo) * n;
 #pragma unroll 1
         for (int j = 0; j < rows; ++j) {
             const PmRowK k = pm_row_tail(R, j), kw = pm_row_tail(RW, j);
@@ -386,17 +401,17 @@ __global__ void rns_extend_edge_pm_kernel(const u64 *__restrict__ in, size_t in_
     }
 }
 
-// layer 0 of the inverse transform (+ n^-1) of all L + K limbs + rescale_k: in [batch][L+K][n] -> out [batch][L][n] (+ addend).
+// layer 0 of the inverse transform (+ n^-1) of all L + K limbs + rescale_k: L q-limbs + K p-limbs (RescaleIn) -> out [batch][L][n] (+ addend).
 // A thread owns the pair (i, i + n/2): with (z0, z1) the pair's values of a limb, the layer gives ((z0 + z1) n^-1, (z0 - z1) twi[1] n^-1)
 // (fft.rs:108-113 `dif`, then fft.rs:73-76).  S0 / S1: the p-limbs' side for the pair's sum / difference (multipliers n^-1 inv_j and
 // n^-1 twi[1] inv_j, hk = half_j inv_j); R.xc[l] = {n^-1 P^-1, n^-1 twi[1] P^-1} of q_l, each cut at 30 bits.
 template <int MAXA, bool FULL>
-__global__ void rns_rescale_edge_pm_kernel(const u64 *__restrict__ in, size_t in_bs, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
+__global__ void rns_rescale_edge_pm_kernel(RescaleIn I, u64 *out, size_t out_bs, const u64 *addend, size_t add_bs,
                                            size_t n, size_t batch, int L, PmSrc S0, PmSrc S1, PmRows R, pd::Uni U) {
     const size_t h = n >> 1, total = h * batch;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t p = idx / h, i = idx - p * h;
-        const u64 *src = in + p * in_bs + i;
+        const u64 *src = I.in_q + p * I.q_bs + i, *psrc = I.in_p + p * I.p_bs + i;
         const u64 *ad = addend ? addend + p * add_bs + i : nullptr;
         u64 *dst = out + p * out_bs + i;
         unsigned a0[MAXA], a1[MAXA], ak[MAXA], b0[MAXA], b1[MAXA], bk[MAXA];
@@ -404,8 +419,8 @@ __global__ void rns_rescale_edge_pm_kernel(const u64 *__restrict__ in, size_t in
         u64 va[MAXA], vb[MAXA];
 #pragma unroll
         for (int j = 0; j < MAXA; ++j) {  // every load in flight before the first product
-            va[j] = (FULL || j < S0.la) ? src[size_t(L + j) * n] : 0;
-            vb[j] = (FULL || j < S0.la) ? src[size_t(L + j) * n + h] : 0;
+            va[j] = (FULL || j < S0.la) ? psrc[I.off[j]] : 0;
+            vb[j] = (FULL || j < S0.la) ? psrc[I.off[j] + h] : 0;
         }
 #pragma unroll
         for (int j = 0; j < MAXA; ++j) {
@@ -455,6 +470,33 @@ FHE_HEADER_KERNEL void rns_pointwise2_kernel(const u64 *__restrict__ e, const u6
             ob[base + i] = mulmod_barrett(x, kb[kbase + i], b);
             oa[base + i] = mulmod_barrett(x, ka[kbase + i], b);
         }
+    }
+}
+
+// the same for a launch whose limbs are a SUBSET of a context's (limb-sharded key switch at n = 1): moduli from the shard's descriptors
+FHE_HEADER_KERNEL void rns_pointwise2_desc_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
+                                                  u64 *__restrict__ ob, u64 *__restrict__ oa, unsigned n, unsigned lk, size_t polys,
+                                                  const ModDesc *__restrict__ D) {
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const unsigned limb = unsigned(y % lk);
+        const Barrett b{D[limb].q, D[limb].bar_mu, D[limb].bar_sh1, D[limb].bar_sh2};
+        const size_t base = y * n, kbase = size_t(limb) * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 x = e[base + i];
+            ob[base + i] = mulmod_barrett(x, kb[kbase + i], b);
+            oa[base + i] = mulmod_barrett(x, ka[kbase + i], b);
+        }
+    }
+}
+// in [groups][nl][n] -> out_q [groups][nq][n], out_p [groups][nl - nq][n] (ring sizes whose inverse transform has no split store)
+FHE_HEADER_KERNEL void rns_split_limbs_kernel(const u64 *__restrict__ in, u64 *__restrict__ out_q, u64 *__restrict__ out_p, size_t n, size_t groups,
+                                              int nl, int nq) {
+    const size_t total = groups * size_t(nl) * n;
+    for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
+        const size_t poly = idx / n, i = idx - poly * n, g = poly / nl;
+        const int l = int(poly - g * nl);
+        if (l < nq) out_q[(g * nq + l) * n + i] = in[idx];
+        else out_p[(g * (nl - nq) + (l - nq)) * n + i] = in[idx];
     }
 }
 

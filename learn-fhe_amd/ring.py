@@ -473,6 +473,39 @@ class CkksKey:
         return ob, oa
 
 
+class CkksShard:
+    """One device's part of a limb-sharded key switch (include/fhe_ring.h fhe_ckks_shard_*): owns the
+    q-limbs [q_lo, q_hi) and the p-limbs [p_lo, p_hi) of `key.rns`."""
+
+    def __init__(self, key: CkksKey, q_lo, q_hi, p_lo, p_hi):
+        self.key, self.rns, self.n = key, key.rns, key.n
+        self.nq, self.np = q_hi - q_lo, p_hi - p_lo
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_ckks_shard_create(key.rns.handle, key._h, q_lo, q_hi, p_lo, p_hi, C.byref(self._h)), "fhe_ckks_shard_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and L is not None and getattr(L, "lib", None):
+            L.lib().fhe_ckks_shard_destroy(h)
+
+    def products(self, ct_a):
+        """stage 1: ct_a [batch][L][n] (replicated) -> (prod_q [2][batch][nq][n], prod_p [2][batch][np][n])"""
+        pa, cnt, mem, st = _buf(ct_a)
+        batch = cnt // (self.rns.L * self.n)
+        pq, pp = _like(ct_a, (2, batch, self.nq, self.n)), _like(ct_a, (2, batch, self.np, self.n))
+        L.check(L.lib().fhe_ckks_shard_products(self._h, pa, _buf(pq)[0], _buf(pp)[0], batch, mem, st), "fhe_ckks_shard_products")
+        return pq, pp
+
+    def finish(self, prod_q, gathered_p, ct_b=None):
+        """stage 2: prod_q, gathered_p [K / np][2][batch][np][n], ct_b [batch][nq][n] or None -> (out_b, out_a) [batch][nq][n]"""
+        pq, cnt, mem, st = _buf(prod_q)
+        batch = cnt // (2 * self.nq * self.n)
+        ob, oa = _like(prod_q, (batch, self.nq, self.n)), _like(prod_q, (batch, self.nq, self.n))
+        pb = _buf(ct_b)[0] if ct_b is not None else None
+        L.check(L.lib().fhe_ckks_shard_finish(self._h, pq, _buf(gathered_p)[0], pb, _buf(ob)[0], _buf(oa)[0], batch, mem, st), "fhe_ckks_shard_finish")
+        return ob, oa
+
+
 # ---- row T: TFHE torus path ------------------------------------------------------------------------------
 
 

@@ -101,3 +101,42 @@ def ckks_key_switch_limb_sharded(ops, rank, world, n, ct_b_limb, ct_a_all, ksk_b
     b = ops.rescale_my_q(pb_q, gathered[:, 0], n)
     a = ops.rescale_my_q(pa_q, gathered[:, 1], n)
     return ops.add_my_q(b, ct_b_limb), a
+
+
+# ---- the same partition on the library's own sharded entry points: a BATCH of ciphertexts per call, the fused kernels -----------
+#
+# fhe_ckks_shard_products / fhe_ckks_shard_finish (include/fhe_ring.h): every rank holds the context and the prepared key and owns
+# a contiguous slice of the q-limbs and of the p-limbs; per batch ONE all-gather of the p-limb products ([2][batch][np][n] per rank)
+# and nothing else crosses ranks.  Under nccl the gather is RCCL on device buffers with no host synchronisation around it.
+
+
+def limb_slices(big_l, big_k, rank, world):
+    """(q_lo, q_hi, p_lo, p_hi) of `rank`: contiguous, every limb owned once; K must split evenly (the gather's contributions are equal)."""
+    if big_k % world:
+        raise ValueError("K = %d p-limbs do not split evenly over %d ranks" % (big_k, world))
+    q_lo, q_hi = shard_range(big_l, rank, world)
+    np_ = big_k // world
+    return q_lo, q_hi, rank * np_, (rank + 1) * np_
+
+
+def all_gather_into(x, group=None):
+    """[...] per rank -> [world][...] on every rank.  nccl: one RCCL all-gather on device memory, asynchronous w.r.t. the host;
+    gloo (CPU ranks, or rehearsals where the ranks share one GPU): through host memory."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+    out = [torch.empty_like(x, device="cpu") for _ in range(world)]
+    dist.all_gather(out, x.cpu().contiguous(), group=group)
+    return torch.stack(out, dim=0).to(x.device)
+
+
+def ckks_key_switch_sharded_batch(shard, ct_b_mine, ct_a_all, all_gather=all_gather_into):
+    """One rank's part for a batch: shard = fhe.CkksShard of this rank; ct_b_mine [batch][nq][n] (ct.b's owned limbs), ct_a_all
+    [batch][L][n] (ct.a, replicated) -> (b', a') [batch][nq][n], the owned limbs of the switched ciphertexts."""
+    prod_q, prod_p = shard.products(ct_a_all)
+    gathered = all_gather(prod_p)  # [world][2][batch][np][n]: the only exchange on the path
+    return shard.finish(prod_q, gathered, ct_b_mine)

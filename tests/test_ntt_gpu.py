@@ -256,6 +256,24 @@ def test_c_program_sharding_over_devices(tmp_path, fhe):
     assert r.returncode == 0 and "multi_gpu_demo ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_c_program_limb_sharded_key_switch(tmp_path, fhe):
+    """examples/multi_gpu_ckks_demo.c: SURVEY.md 8(e) row 3 at the C boundary -- cfg4's key switch with its limbs sharded over the
+    devices of ONE process (two shards on two streams of the device on a one-GPU box): fhe_ckks_shard_products, the caller's own
+    gather by hipMemcpyPeerAsync + events (no host synchronisation in between), fhe_ckks_shard_finish; every output limb bit-equal
+    to the single-device fhe_ckks_key_switch"""
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.dirname(fhe.lib_path())
+    exe = tmp_path / "multi_gpu_ckks_demo"
+    cmd = ["gcc", "-std=c99", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "multi_gpu_ckks_demo.c"), "-o", str(exe), "-L", lib_dir, "-lfhe_ring", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "multi_gpu_ckks_demo ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_scratch_pool_is_private_and_trimmable(fhe, torch_cuda):
     """device scratch comes from the library's own stream-ordered pool (api_common.hpp), not the device's default pool: a
     host-memory call and a workspace-using device call leave the default pool's release threshold alone; fhe_trim() succeeds"""

@@ -294,6 +294,93 @@ def test_ckks_key_switch_limb_sharded(tmp_path, world, log_n):
     assert r.stdout.count("ok") == world
 
 
+@pytest.mark.parametrize("log_n,bits,big_l,big_k,shards,batch", [(15, 60, 8, 8, 8, 3), (15, 60, 4, 4, 2, 8), (15, 60, 9, 3, 3, 2), (14, 60, 4, 2, 2, 3),
+                                                                   (13, 60, 4, 4, 4, 2), (10, 55, 4, 4, 4, 3), (4, 50, 3, 3, 3, 2), (0, 50, 2, 2, 2, 2), (0, 45, 2, 2, 2, 2)])
+def test_ckks_shard_entries_equal_the_key_switch(fhe, cref, torch_cuda, log_n, bits, big_l, big_k, shards, batch):
+    """fhe_ckks_shard_products / fhe_ckks_shard_finish (SURVEY.md section 8(e) row 3 behind the C ABI): `shards` owners of contiguous
+    q- and p-limb slices, each running its two stages on a BATCH with the fused kernels, the p-limb products gathered in between --
+    every owned output limb bit-equal to fhe_ckks_key_switch on the whole ciphertext and to the oracle.  Covers the 2^15 edge route
+    (layer 0 of the transforms inside extend / rescale), whole-transform 2^15 (L > 8), the split store of the wave-local inverse
+    (2^13, 2^14), the pack fallback (2^10, 2^4, n = 1), ragged q-slices (9 limbs over 3 shards) and a base that is not pseudo-Mersenne."""
+    from learn_fhe_amd.shard import limb_slices
+    torch = torch_cuda
+    n = 1 << log_n
+    primes = cref.two_adic_primes(bits, max(log_n + 1, 17 if bits == 45 else 1), big_l + big_k)
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    kb, ka = rand_limbs(61, qs + ps, n), rand_limbs(62, qs + ps, n)
+    cb, ca = rand_limbs(63, qs, n, batch), rand_limbs(64, qs, n, batch)
+    key = fhe.CkksKey(rns, dev(torch, kb), dev(torch, ka), n)
+    if bits == 45:  # two_adic_primes(45, 17): 2^45 - q is too large for the two-operand products -> no limb subsets on the Shoup route
+        with pytest.raises(fhe.FheError):
+            fhe.CkksShard(key, 0, 1, 0, 1)
+        return
+    b, a = dev(torch, cb), dev(torch, ca)
+    key.key_switch_(b, a)
+    owners = [fhe.CkksShard(key, *limb_slices(big_l, big_k, r, shards)) for r in range(shards)]
+    d_a = dev(torch, ca)
+    stage1 = [o.products(d_a) for o in owners]
+    gathered = torch.stack([pp for _, pp in stage1], dim=0).contiguous()  # what the all-gather leaves on every device
+    for r, o in enumerate(owners):
+        q_lo, q_hi, _, _ = limb_slices(big_l, big_k, r, shards)
+        ob, oa = o.finish(stage1[r][0], gathered, dev(torch, np.ascontiguousarray(cb[:, q_lo:q_hi])))
+        assert np.array_equal(host(ob), host(b)[:, q_lo:q_hi]) and np.array_equal(host(oa), host(a)[:, q_lo:q_hi]), r
+    eb, ea = cref.ckks_key_switch(qs, ps, kb, ka, cb[batch - 1], ca[batch - 1])
+    assert np.array_equal(host(b)[batch - 1], eb) and np.array_equal(host(a)[batch - 1], ea)
+
+
+SHARDED_BATCH_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+import torch.distributed as dist
+import learn_fhe_amd as F
+from learn_fhe_amd.shard import limb_slices, ckks_key_switch_sharded_batch
+from oracle import cref
+dist.init_process_group(backend="gloo")                    # one GPU on this box: every rank drives cuda:0, gloo carries the gather
+rank, world = dist.get_rank(), dist.get_world_size()
+log_n, batch = %d, 8
+n = 1 << log_n
+primes = cref.two_adic_primes(60, log_n + 1, 2 * world)
+qs, ps = primes[:world], primes[world:]
+rng = np.random.Generator(np.random.PCG64(18))             # same seed on every rank: replicated inputs
+limbs = lambda mods, *lead: np.stack([rng.integers(0, m, size=(*lead, n), dtype=np.uint64) for m in mods], axis=len(lead))
+ksk_b, ksk_a, ct_b, ct_a = limbs(qs + ps), limbs(qs + ps), limbs(qs, batch), limbs(qs, batch)
+D = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+H = lambda t: t.cpu().numpy().view(np.uint64)
+rns = F.RnsContext(qs, ps)
+key = F.CkksKey(rns, D(ksk_b), D(ksk_a), n)
+q_lo, q_hi, p_lo, p_hi = limb_slices(world, world, rank, world)
+shard = F.CkksShard(key, q_lo, q_hi, p_lo, p_hi)
+b, a = ckks_key_switch_sharded_batch(shard, D(ct_b[:, q_lo:q_hi]), D(ct_a))
+for c in (0, batch - 1):
+    eb, ea = cref.ckks_key_switch(qs, ps, ksk_b, ksk_a, ct_b[c], ct_a[c])
+    assert np.array_equal(H(b)[c], eb[q_lo:q_hi]) and np.array_equal(H(a)[c], ea[q_lo:q_hi]), "limb-sharded batch key switch != oracle"
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 13), (4, 15)])
+def test_ckks_key_switch_limb_sharded_batch(tmp_path, world, log_n):
+    """The batched, fused limb-sharded key switch (fhe_ckks_shard_*) across PROCESSES: `world` ranks share this box's GPU, gloo carries
+    the one all-gather of the p-limb products (under nccl the same call is one RCCL all-gather on device memory); batch 8, every rank's
+    owned limbs of the first and last ciphertext bit-exact against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "sharded_batch_worker.py"
+    script.write_text(SHARDED_BATCH_WORKER % (ROOT, log_n))
+    port = str(29650 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", port, str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
+
+
 # ---- homomorphic CKKS operations on top of the key switch (SURVEY.md section 8(f) rank 2) ----------------------------------
 
 @pytest.mark.parametrize("log_n,bits,big_l,big_k", [(4, 50, 3, 3), (10, 55, 4, 2), (13, 60, 2, 2), (14, 60, 3, 1)])
