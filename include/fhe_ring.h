@@ -52,7 +52,8 @@ int fhe_trim(void);
  * result.  Each is read ONCE from the environment (FHE_RING_<NAME>) and afterwards only through this call: the library never calls
  * getenv on a call path.  Names: "NO_EDGE" (key switch at N = 2^15 on whole transforms), "NO_LIMB_MAJOR" (linear dispatch order over
  * several moduli), "NO_W12" (2^12 / 2^13 rings on the generic kernels), "NO_FUSED_MUL" (ring product as forward + multiplying
- * inverse), "SMALL_BATCH" (FHEW: 4 coefficients per lane up to this batch, 8 above; -1 = the library's rule).  Unknown name:
+ * inverse), "SMALL_BATCH" (FHEW: 4 coefficients per lane up to this batch, 8 above; -1 = the library's rule), "NO_PACKED_DIGITS" (TFHE blind
+ * rotation: digits decomposed once per prime instead of once per CMUX).  Unknown name:
  * FHE_ERR_INVALID. */
 int fhe_set_option(const char *name, long value);
 

@@ -17,6 +17,7 @@ struct Mod30Desc {              // one prime p < 2^30, p = 1 (mod 2^12); tables 
     unsigned ninv[12], ninv_s[12];  // (2^k)^-1 mod p and its companion
     unsigned pinv_neg;          // -p^-1 mod 2^32 (Montgomery)
     unsigned r2;                // 2^64 mod p: x -> x 2^32 mod p via one Montgomery product
+    unsigned r1;                // 2^32 mod p: folds a 64-bit sum of products to below 2^32 p before its one Montgomery reduction
 };
 
 __device__ __forceinline__ unsigned csub32(unsigned x, unsigned m) { return min(x, x - m); }  // x < 2m: x mod~ m (x - m wraps huge if x < m)
@@ -36,9 +37,10 @@ struct Arith30 {
         const FHE_CONST uint2 *tw, *twi;  // constant address space: wave-uniform entries become scalar loads
         unsigned ninv, ninv_s, pinv_neg;
         int pb, prefix;
+        unsigned r1;
     };
     static __device__ __forceinline__ K make(const Mod30Desc &D, int log_n) {
-        return K{D.p, 2 * D.p, (const FHE_CONST uint2 *)D.tw, (const FHE_CONST uint2 *)D.twi, D.ninv[log_n], D.ninv_s[log_n], D.pinv_neg, 0, 0};
+        return K{D.p, 2 * D.p, (const FHE_CONST uint2 *)D.tw, (const FHE_CONST uint2 *)D.twi, D.ninv[log_n], D.ninv_s[log_n], D.pinv_neg, 0, 0, D.r1};
     }
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
@@ -77,6 +79,14 @@ struct Arith30 {
     }
     static __device__ __forceinline__ MacAcc mac(MacAcc acc, unsigned xin, unsigned kmont, const K &k) {
         return csub32(acc + redc((u64)xin * kmont, k), k.p2);
+    }
+    // The same sum UNREDUCED: every term is one v_mad_u64_u32 into a 64-bit accumulator (x in [0, 2p) < 2^31, key < p < 2^30: a
+    // product is below 2 p^2 < 2^61, eight terms stay below 2^64), and ONE reduction per output closes it: S = hi 2^32 + lo =
+    // hi r1 + lo (mod p) < 2^62 + 2^32, whose Montgomery reduction is below 2^30 + 1 + p -- one conditional subtraction of 2p
+    // leaves a valid inverse-transform input in [0, 2p).  6 instructions per term become 1, plus 5 per output.
+    static __device__ __forceinline__ unsigned mac_close(u64 s, const K &k) {
+        const u64 t = (u64)(unsigned)(s >> 32) * k.r1 + (unsigned)s;
+        return csub32(redc(t, k), k.p2);
     }
 };
 

@@ -188,6 +188,9 @@ struct WaveRing {
     static constexpr size_t LDS_BYTES = size_t(PN + (PARK ? N : 0)) * 8 * TEAMS;
     static constexpr int TORUS_LDS_WORDS = PN + 2 * N;  // torus kernels: exchange image + parking area for one residue pair
     static constexpr size_t TORUS_LDS_BYTES = size_t(TORUS_LDS_WORDS) * 8 * TEAMS;
+    // 30-bit torus blind rotation with the digits of a CMUX parked as bytes (torus30_kernels.hpp): + [limbs][E / 4][TEAM] dwords
+    static __host__ __device__ constexpr int torus_dig_words(int limbs) { return E >= 4 ? limbs * (E / 4) * TEAM / 2 : 0; }  // in 8-byte words
+    static __host__ __device__ constexpr size_t torus_pk_lds_bytes(int limbs) { return size_t(TORUS_LDS_WORDS + torus_dig_words(limbs)) * 8 * TEAMS; }
 #ifndef FHE_TEAM_OCC
 #define FHE_TEAM_OCC 2
 #endif

@@ -207,6 +207,156 @@ __global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void torus30_blind_rotate
     wave_store<W>(cb, out_b + size_t(ct) * N, lane);
 }
 
+// ---- the blind rotation with a CMUX's digits computed ONCE (log_b <= 8, 2d <= 8: BASELINE config 5's gadget) --------------------
+// The kernels above decompose (da, db) three times, once per prime, and keep (da, db) and the decomposition state in registers
+// across all three passes: 48 registers, and a third of the decomposition work repeated twice.  A digit of a base <= 2^8 gadget
+// is a signed byte: here the 2d E digits of a lane are computed once, packed four to a dword and parked in a lane-private LDS
+// area ([limb][E / 4][TEAM] dwords: consecutive lanes on consecutive banks); each prime's pass unpacks them with one
+// v_bfe_i32 each.  The registers that frees hold the multiply-accumulate's sums UNREDUCED (Arith30::mac_close).  Same integers
+// mod every prime, same CRT: the outputs are bit-identical to the kernels above (tests/test_torus_gpu.py runs both).
+template <class W>
+__device__ __forceinline__ void park_digits30(const u64 (&da)[W::E], const u64 (&db)[W::E], const TDecomp &P, int lane, unsigned *dig) {
+    constexpr int E = W::E;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        u64 st[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[e] = tdecomp_init(half ? db[e] : da[e], P);
+#pragma unroll 1
+        for (int j = 0; j < P.d; ++j) {
+#pragma unroll
+            for (int r4 = 0; r4 < E / 4; ++r4) {
+                unsigned w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w |= ((unsigned)tdecomp_next(st[4 * r4 + b], P) & 0xffu) << (8 * b);  // |digit| <= 2^(log_b-1) <= 128... the byte
+                dig[((half * P.d + j) * (E / 4) + r4) * W::TEAM + lane] = w;
+            }
+        }
+    }
+}
+
+template <class W>
+__device__ __forceinline__ void team_torus_gadget30_pk(const unsigned *dig, const unsigned *__restrict__ rows, int d2, int lane, unsigned *lds,
+                                                       const Arith30::K &k, unsigned (&sa)[W::E], unsigned (&sb)[W::E]) {
+    using A = Arith30;
+    constexpr int E = W::E;
+    u64 acc_a[E], acc_b[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc_a[e] = acc_b[e] = 0;
+    KeyRow30<W> kr;
+    load_row30<W>(kr, rows, lane);
+#pragma unroll 1
+    for (int j = 0; j < d2; ++j) {
+        const int ln = lane;
+        unsigned x[E];
+#pragma unroll
+        for (int r4 = 0; r4 < E / 4; ++r4) {
+            const unsigned w = dig[(j * (E / 4) + r4) * W::TEAM + ln];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned dg = (unsigned)((int)(w << (24 - 8 * b)) >> 24);  // sign-extended byte
+                x[4 * r4 + b] = min(dg, dg + k.p);                             // negative digits wrap to huge: + p brings them into [0, p)
+            }
+        }
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, ln, nullptr, lds, true, k);
+#pragma unroll
+        for (int r4 = 0; r4 < E / 4; ++r4) {
+            const uint4 a = kr.a[r4], b = kr.b[r4];
+            const unsigned ka[4] = {a.x, a.y, a.z, a.w}, kb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned xe = csub32(x[4 * r4 + i], k.p2);  // lazy forward output [0, 4p) -> [0, 2p)
+                acc_a[4 * r4 + i] += (u64)xe * ka[i];
+                acc_b[4 * r4 + i] += (u64)xe * kb[i];
+            }
+        }
+        if (j + 1 < d2) load_row30<W>(kr, rows + size_t(j + 1) * 2 * W::N, ln);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sa[e] = A::mac_close(acc_a[e], k); sb[e] = A::mac_close(acc_b[e], k); }
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        const int ln = lane;
+        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, ln, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const unsigned t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
+    }
+}
+
+template <class W>
+__device__ __forceinline__ void team_torus_cmux30_pk(u64 (&ca)[W::E], u64 (&cb)[W::E], unsigned r, const unsigned *__restrict__ rows0,
+                                                     const unsigned *__restrict__ rows1, const unsigned *__restrict__ rows2, const TDecomp &P,
+                                                     const Torus30Consts &T, int lane, u64 *lds64) {
+    constexpr int E = W::E;
+    if (r == 0) return;  // team-uniform
+    unsigned *dig = reinterpret_cast<unsigned *>(lds64 + W::TORUS_LDS_WORDS);
+    {
+        u64 da[E], db[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { da[e] = ca[e]; db[e] = cb[e]; }
+        team_torus_rotate<W>(da, r, lane, lds64);
+        team_torus_rotate<W>(db, r, lane, lds64);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
+        park_digits30<W>(da, db, P, lane, dig);
+    }
+    unsigned *lds = reinterpret_cast<unsigned *>(lds64);
+    unsigned *park = reinterpret_cast<unsigned *>(lds64 + W::PN);
+    unsigned sa[E], sb[E];
+    const unsigned *rows[3] = {rows0, rows1, rows2};
+#pragma unroll 1
+    for (int pr = 0; pr < 3; ++pr) {
+        const Arith30::K k = Arith30::make(T.descs[pr], W::LOG_N);
+        team_torus_gadget30_pk<W>(dig, rows[pr], 2 * P.d, lane, lds, k, sa, sb);
+        if (pr < 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                park[((pr * 2 + 0) * E + e) * W::TEAM + lane] = sa[e];
+                park[((pr * 2 + 1) * E + e) * W::TEAM + lane] = sb[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        ca[e] += crt3_mod64(park[((0 * 2 + 0) * E + e) * W::TEAM + lane], park[((1 * 2 + 0) * E + e) * W::TEAM + lane], sa[e], T);
+        cb[e] += crt3_mod64(park[((0 * 2 + 1) * E + e) * W::TEAM + lane], park[((1 * 2 + 1) * E + e) * W::TEAM + lane], sb[e], T);
+    }
+}
+
+// Compiled for two waves per SIMD like the kernel above (204 registers at N = 2^10: FOUR teams per CU, a batch of 1024 is exactly one
+// generation of 256 CUs).  Measured and dropped: three waves per SIMD -- 159 registers once the lane index is made opaque per limb so
+// that the transforms' exchange addresses are recomputed instead of living across the loop, and with the digit area sized by the
+// gadget (31 232 bytes per team) FIVE teams per CU: 17.1 k gates/s at batch 1024 against 25.5 k (a fifth team per CU leaves 52 CUs of
+// that batch idle), 20.8 k against 21.8 k at 1280, 21.8 k against 26.4 k at 4096 -- recomputed addresses cost more than a fifth team hides.
+template <class W>
+__global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void torus30_blind_rotate_pk_kernel(
+    const u64 *__restrict__ v, const u64 *__restrict__ a_tilde, const u64 *__restrict__ b_tilde, unsigned n_lwe, unsigned batch,
+    const unsigned *__restrict__ rows, size_t plane, TDecomp P, Torus30Consts T, u64 *__restrict__ out_a, u64 *__restrict__ out_b) {
+    constexpr int E = W::E, N = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    if (ct >= batch) return;
+    // a team's LDS: exchange image | parking area of two residue pairs | the digits of one CMUX, sized by the gadget (2d limbs): at
+    // cfg5 (N = 2^10, d = 3) 31 232 bytes -- FIVE teams per CU where the 8-limb maximum would leave room for four
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * (W::TORUS_LDS_WORDS + W::torus_dig_words(2 * P.d));
+    u64 ca[E], cb[E];
+    wave_load<W>(cb, v, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) ca[e] = 0;
+    team_torus_rotate<W>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);
+    const size_t per = size_t(2 * P.d) * 2 * N;
+    const u64 *a = a_tilde + size_t(ct) * n_lwe;
+#pragma unroll 1
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const unsigned r = __builtin_amdgcn_readfirstlane(unsigned(a[i]) & (2 * N - 1));
+        const unsigned *k0 = rows + i * per;
+        team_torus_cmux30_pk<W>(ca, cb, r, k0, k0 + plane, k0 + 2 * plane, P, T, lane, lds);
+    }
+    wave_store<W>(ca, out_a + size_t(ct) * N, lane);
+    wave_store<W>(cb, out_b + size_t(ct) * N, lane);
+}
+
 // key preparation for one prime: signed torus rows [rows][2][N] (a | b) -> Montgomery-form evaluations in key_perm30 layout
 template <class W>
 __global__ __launch_bounds__(W::THREADS) void torus30_key_prepare_kernel(const u64 *__restrict__ rows_a, const u64 *__restrict__ rows_b, size_t n_rows,

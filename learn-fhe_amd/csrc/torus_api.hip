@@ -90,6 +90,7 @@ void build_host30(Host30 &H) {
         for (int it = 0; it < 5; ++it) inv *= 2 - (uint32_t)p * inv;
         D.pinv_neg = 0u - inv;
         D.r2 = (uint32_t)((((fhe::u128)1) << 64) % p);
+        D.r1 = (uint32_t)((uint64_t(1) << 32) % p);
     }
 }
 
@@ -458,6 +459,26 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     int rc = FHE_OK;
     if (brk->d_rows30) {  // three 30-bit primes
         const size_t plane = brk->count * size_t(2 * brk->d) * 2 * n;
+        // base <= 2^8 and at most 8 limbs (cfg5: base 2^7, d = 3): the CMUX digits are computed once and parked as bytes, the
+        // multiply-accumulate runs unreduced (torus30_kernels.hpp); lab switch NO_PACKED_DIGITS keeps the older kernel (bit-identical)
+        // (a digit of base 2^8 ranges over [-128, 128]: one value too many for a byte)
+        const bool packed = brk->P.log_b <= 7 && 2 * brk->d <= 8 && brk->log_n >= 8 && fhe::opt(fhe::OPT_NO_PACKED_DIGITS) == 0;
+        if (packed) {
+            TORUS_DISPATCH(brk->log_n, {
+                typedef TorusRing30<LN> WR;
+                const size_t lds = WR::torus_pk_lds_bytes(2 * brk->d);
+                if (lds > 64 * 1024) {
+                    static std::atomic<int> done{0};
+                    if (!done.load(std::memory_order_acquire)) {
+                        HIP_TRY(hipFuncSetAttribute((const void *)fhe::torus30_blind_rotate_pk_kernel<WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        done.store(1, std::memory_order_release);
+                    }
+                }
+                hipLaunchKernelGGL(fhe::torus30_blind_rotate_pk_kernel<WR>, dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), lds, st,
+                                   (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe, (unsigned)batch,
+                                   (const unsigned *)brk->d_rows30, plane, brk->P, t->T30, moa.d, mob.d);
+            });
+        } else
         TORUS_DISPATCH(brk->log_n, {
             typedef TorusRing30<LN> WR;
             const size_t lds = WR::TORUS_LDS_BYTES;

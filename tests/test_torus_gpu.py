@@ -404,3 +404,36 @@ def test_cmux_and_rotate_entries(fhe, torch_cuda, log_n, log_b, d):
         ra_, rb_ = cref.torus_monomial_mul(c0a[i], a_t), cref.torus_monomial_mul(c0b[i], a_t)
         ea, eb = cref.tggsw_external_product(log_b, d, ra[0], rb[0], ra_ - c0a[i], rb_ - c0b[i])
         assert np.array_equal(host(sa)[i], c0a[i] + ea) and np.array_equal(host(sb)[i], c0b[i] + eb)
+
+
+@pytest.mark.parametrize("log_n,log_b,d,batch", [(10, 7, 3, 5), (10, 7, 4, 3), (10, 8, 3, 2), (9, 6, 2, 4), (8, 4, 4, 6), (11, 7, 2, 2)])
+def test_packed_digit_blind_rotation_equals_the_unpacked_one(fhe, torch_cuda, log_n, log_b, d, batch):
+    """Gadgets of base <= 2^7 (a digit of base 2^8 reaches +128: no byte) and at most 8 limbs run the blind rotation with each CMUX's digits computed once and parked as bytes, and
+    the multiply-accumulate unreduced (torus30_kernels.hpp, `_pk` kernels); the lab switch NO_PACKED_DIGITS keeps the kernel that
+    decomposes once per prime.  Same integers, same CRT: bit-identical accumulators -- incl. extreme inputs (digits at both ends of
+    their range, key words -2^63) -- and (cfg5's shape) equal to the exact oracle."""
+    from oracle import cref
+    n, n_lwe = 1 << log_n, 7
+    rng = np.random.Generator(np.random.PCG64(100 + log_n + d))
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)  # noqa: E731
+    ra, rb, v = r64(n_lwe, 2 * d, n), r64(n_lwe, 2 * d, n), r64(n)
+    ra[0, :, :] = np.uint64(1 << 63)                       # the most negative key words
+    half = 1 << (log_b - 1)
+    v[: n // 2] = np.uint64((-sum(half << (64 - log_b * (j + 1)) for j in range(d))) % (1 << 64))  # every digit at its most negative
+    a_t = rng.integers(0, 2 * n, size=(batch, n_lwe), dtype=np.uint64)
+    a_t[0, 0] = 0                                          # a rotation by zero short-circuits
+    b_t = rng.integers(0, 2 * n, size=batch, dtype=np.uint64)
+    t = fhe.TorusContext()
+    key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+    outs = []
+    for off in (0, 1):  # the packed kernel | the older one
+        fhe.set_option("NO_PACKED_DIGITS", off)
+        try:
+            outs.append(key.blind_rotate(dev(torch_cuda, a_t), dev(torch_cuda, b_t), dev(torch_cuda, v)))
+        finally:
+            fhe.set_option("NO_PACKED_DIGITS", 0)
+    for o in outs[1:]:
+        assert torch_cuda.equal(outs[0][0], o[0]) and torch_cuda.equal(outs[0][1], o[1])
+    if (log_n, log_b, d) == (10, 7, 3):
+        ea, eb = cref.tfhe_blind_rotate(log_b, d, ra, rb, v, a_t, b_t, threads=8)
+        assert np.array_equal(host(outs[0][0]).reshape(batch, n), ea) and np.array_equal(host(outs[0][1]).reshape(batch, n), eb)
