@@ -456,6 +456,11 @@ __global__ void rns_rescale_edge_pm_kernel(RescaleIn I, u64 *out, size_t out_bs,
     }
 }
 
+// Measured and dropped (round 3, per 64 cfg4 ciphertexts, pair form above: 112 us, 52 % of its wave cycles parked on loads with 4 loads
+// in flight per thread): (i) ONE coefficient per lane, the butterfly partner at lane ^ 32 -- 105 registers (the lane halves select
+// their constants), still four waves per SIMD: 119 us; (ii) the pair form with the row loop's operands requested two limbs ahead
+// and the Karatsuba sums y0 + y1 formed per use to pay for it -- the allocator spills (164 bytes of scratch per lane): 238 us.
+
 // ob = kb (.) e, oa = ka (.) e limb-wise in the evaluation domain; e, ob, oa: [batch][lk][n]; kb, ka: [lk][n].
 // blockIdx.y = (ciphertext, limb): the limb's Barrett constants come from scalar loads and no thread divides anything
 FHE_HEADER_KERNEL void rns_pointwise2_kernel(const u64 *__restrict__ e, const u64 *__restrict__ kb, const u64 *__restrict__ ka,
