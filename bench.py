@@ -171,9 +171,12 @@ def fhew_bench(torch, F, dev, local_rank, batches=(1, 64, 1024, 4096), reps=3, v
     if n_auto is not None:
         br_bytes = n_lwe * ep_bytes + n_auto * ks_bytes
         out["automorphism_key_switches_per_blind_rotation"] = n_auto
-        out["roofline"] = roof(out["blind_rotations_per_sec_batch1024"], br_bytes, "blind_rotate_kernel<ArithDS<54>, WaveRing<10, 3>> (batch 1024)",
+        top = max(batches)  # the largest resident batch (4096: the 4-coefficients-per-lane form, four waves per SIMD); batch 1024 beside it
+        out["roofline"] = roof(out["blind_rotations_per_sec_batch%d" % top], br_bytes, "blind_rotate_kernel<ArithDS<54>, WaveRing<10, 2>> (batch %d)" % top,
                                "%d external products x %d B + %.1f automorphism key switches x %d B per blind rotation; keys cache resident"
                                % (n_lwe, ep_bytes, n_auto, ks_bytes))
+        if 1024 in batches:
+            out["roofline_batch1024"] = roof(out["blind_rotations_per_sec_batch1024"], br_bytes, "blind_rotate_kernel<ArithDS<54>, WaveRing<10, 3>> (batch 1024: one generation of 256 CUs)")
     return out
 
 
@@ -193,12 +196,13 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3, verify=True):
     kb_raw, ka_raw = limbs(qs + ps), limbs(qs + ps)
     key = F.CkksKey(rns, kb_raw, ka_raw, n)
     out = {"workload": "cfg4: CKKS key switch N=2^15, 8+8 60-bit primes"}
-    for b in (batch, 8 * batch):
+    big = 32 * batch  # 256 ciphertexts: the resident batch the roofline figure is quoted on (launch ramps and tails weigh ~6 % at 64)
+    for b in (batch, 8 * batch, big):
         cb, ca = limbs(qs, b), limbs(qs, b)
         cb0, ca0 = cb.clone(), ca.clone()
         dt = _timeit(torch, lambda: key.key_switch_(cb, ca), max(reps, 10 if b >= 64 else reps))
         out["key_switches_per_sec_batch%d" % b] = b / dt
-        if verify and b == 8 * batch:  # one launch sequence of the timed shape on the untouched inputs, first and last ciphertext against the CPU oracle
+        if verify and b == big:  # one launch sequence of the timed shape on the untouched inputs, first and last ciphertext against the CPU oracle
             import numpy as np
             from oracle import cref
             u = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
@@ -210,7 +214,7 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3, verify=True):
                 ok = ok and np.array_equal(u(wb[i]), eb) and np.array_equal(u(wa[i]), ea)
             out["verified"] = bool(ok)
             out["verification"] = "key switch at batch %d: ciphertexts 0 and %d, all 2 x 8 output limbs bit-equal to the CPU oracle" % (b, b - 1)
-        del cb0, ca0
+        del cb0, ca0, cb, ca
     # `Ckks::mul` (ckks.rs:250-263: tensor + relinearisation + rescale) on the same parameter set, 7 L transforms + one key switch
     b = 2 * batch
     c4 = [limbs(qs, b) for _ in range(4)]
@@ -218,9 +222,9 @@ def ckks_bench(torch, F, dev, local_rank, batch=8, reps=3, verify=True):
     out["muls_per_sec_batch%d" % b] = b / dt
     del c4
     # ct in 2L 8N + ksk 2(L+K) 8N + ct out 2L 8N = 16 MiB at cfg4
-    out["roofline"] = roof(out["key_switches_per_sec_batch%d" % (8 * batch)], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
+    out["roofline"] = roof(out["key_switches_per_sec_batch%d" % big], (2 * big_l + 2 * 2 * big_l + 2 * big_l) * 8 * n,
                            "rns_extend_edge (base extension + layer 0 of the forward transforms) + ntt14w_fwd<PFX> + ntt14w_inv<PFX, MUL> (2^14 sub-transforms, two workgroups per CU; ksk products fused into the inverse's load) + rns_rescale_edge x2 (layer 0 of the inverse transforms, n^-1, rescale_k)",
-                           "the base conversions mix limbs, so extend / transforms / rescales stay separate passes over the limbs: ~4x the algorithmic bytes move")
+                           "batch %d resident; the base conversions mix limbs, so extend / transforms / rescales stay separate passes over the limbs: ~2.7x the algorithmic bytes move" % big)
     return out
 
 
