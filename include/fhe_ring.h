@@ -267,7 +267,7 @@ int fhe_ckks_mul(const fhe_rns_ctx *rns, const fhe_ckks_key *rlk, const uint64_t
                  const uint64_t *ct1_a, uint64_t *out_b, uint64_t *out_a, size_t batch, fhe_mem mem, void *stream);
 
 
-/* ---- TFHE torus path (row T), k = 1 ---------------------------------------------------------------------- */
+/* ---- TFHE torus path (row T), k = 1: fused kernels (any rank k: the fhe_*k_* entries further down) ---------- */
 /* Torus data are uint64_t values of Z/2^64 (util/src/torus.rs `T64`).  Where the reference multiplies torus polynomials
  * with an f64 FFT (util/src/ring/fft/c64.rs:11-56, error <= 2^(64+log_b+log_n-53), c64.rs:186-208), this backend returns
  * the EXACT product (both operands read as signed 64-bit integers, as c64.rs:23-27 does): never less exact than the
@@ -317,6 +317,36 @@ int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t 
 int fhe_tfhe_bootstrap(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, int ks_log_b, int ks_d, const uint64_t *ksk_a,
                        const uint64_t *ksk_b, const uint64_t *v, const uint64_t *lwe_a, const uint64_t *lwe_b, uint64_t *out_a,
                        uint64_t *out_b, size_t batch, fhe_mem mem, void *stream);
+
+/* ---- TFHE torus path at any TGLWE rank k (the reference's `TglweParam::n`: tglwe.rs:11-35; its TGLWE / TGGSW tests run at k = 2,
+ * N = 256, base 2^8, d = 8: tglwe.rs:138-166, tggsw.rs:134-181) ------------------------------------------------------------- */
+/* A rank-k TGLWE ciphertext is ONE buffer [k + 1][n]: a_0 .. a_{k-1}, b (tglwe.rs:49-50 `TglweCiphertext(AVec<Rt>, Rt)`); a TGGSW
+ * ciphertext is (k + 1) d of them in the order tggsw.rs:80-87 builds (message on a_0: d rows, .., on a_{k-1}, on b).  Products are
+ * the exact ones of the k = 1 entries; k = 1 through these entries gives bit-identical results.  1 <= k <= 8, n = 2 .. 2^15. */
+typedef struct fhe_tggswk_key fhe_tggswk_key;
+/* rows [count][(k + 1) d][k + 1][n] -> prepared (evaluation-domain) key; FHE_ERR_UNSUPPORTED if (k + 1) d n 2^(62 + log_b) >= 2^118 */
+int fhe_tggswk_prepare(const fhe_torus_ctx *t, int k, int log_b, int d, const uint64_t *rows, size_t n, size_t count, fhe_mem mem,
+                       fhe_tggswk_key **out);
+void fhe_tggswk_key_destroy(fhe_tggswk_key *key);
+/* tggsw.rs:100-112 `Tggsw::external_product(param, key[index], ct)`, in place on ct [batch][k + 1][n] */
+int fhe_tggswk_external_product(const fhe_torus_ctx *t, const fhe_tggswk_key *key, size_t index, uint64_t *ct, size_t batch, fhe_mem mem,
+                                void *stream);
+/* tggsw.rs:114-121 `Tggsw::cmux(key[index], ct0, ct1)`; [batch][k + 1][n] each, out may alias ct0 or ct1 */
+int fhe_tggswk_cmux(const fhe_torus_ctx *t, const fhe_tggswk_key *key, size_t index, const uint64_t *ct0, const uint64_t *ct1, uint64_t *out,
+                    size_t batch, fhe_mem mem, void *stream);
+/* tglwe.rs:61-66 `TglweCiphertext::rotate(i)`; ct, out [batch][k + 1][n], out != ct */
+int fhe_tglwek_rotate(const uint64_t *ct, int k, size_t n, int64_t i, uint64_t *out, size_t batch, fhe_mem mem, void *stream);
+/* tglwe.rs:115-127 `Tglwe::sample_extract(ct, index)`: a TLWE ciphertext of dimension k n: out_a [batch][k n], out_b [batch] */
+int fhe_tglwek_sample_extract(const uint64_t *ct, int k, size_t n, size_t index, uint64_t *out_a, uint64_t *out_b, size_t batch, fhe_mem mem,
+                              void *stream);
+/* bootstrapping.rs:84-96 `blind_rotate`: a_tilde [batch][n_lwe], b_tilde [batch] mod-switched, v [n] encoded -> out [batch][k + 1][n] */
+int fhe_tfhek_blind_rotate(const fhe_torus_ctx *t, const fhe_tggswk_key *brk, const uint64_t *a_tilde, const uint64_t *b_tilde, const uint64_t *v,
+                           uint64_t *out, size_t batch, fhe_mem mem, void *stream);
+/* bootstrapping.rs:78-82 `Bootstrapping::bootstrap`: mod switch -> blind rotation -> sample_extract(0) -> key switch with
+ * n_in = k n, n_out = n_lwe (ksk_a [k n ks_d][n_lwe], ksk_b [k n ks_d]); lwe_a, out_a [batch][n_lwe], lwe_b, out_b [batch] */
+int fhe_tfhek_bootstrap(const fhe_torus_ctx *t, const fhe_tggswk_key *brk, int ks_log_b, int ks_d, const uint64_t *ksk_a, const uint64_t *ksk_b,
+                        const uint64_t *v, const uint64_t *lwe_a, const uint64_t *lwe_b, uint64_t *out_a, uint64_t *out_b, size_t batch,
+                        fhe_mem mem, void *stream);
 
 /* ---- key material on the device ------------------------------------------------- */
 /* Randomness.  Every producer below draws from an `fhe_rng`: a 256-bit ChaCha20 key.  Value i of a draw is a word of ChaCha20
@@ -381,7 +411,7 @@ int fhe_ckks_sk_encrypt(const fhe_rns_ctx *rns, int extended, const uint64_t *sk
 int fhe_ckks_ksk_gen(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *sk_prime, size_t n, const fhe_rng *rng, uint64_t stream_id,
                      uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream);
 
-/* ---- TFHE key material, k = 1.  Draws are counter based (ChaCha20, as above): reproducible per
+/* ---- TFHE key material, k = 1 (rank k: fhe_tglwek_sk_encrypt / fhe_tggswk_encrypt at the end).  Draws are counter based (ChaCha20, as above): reproducible per
  * (generator key, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
 /* util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: torus Gaussian noise (Box-Muller deviate, fractional part scaled by 2^64) */
 int fhe_sample_tdg(double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *out, size_t count, fhe_mem mem, void *stream);
@@ -400,6 +430,14 @@ int fhe_tglwe_sk_encrypt(const fhe_torus_ctx *t, const uint64_t *sk, const uint6
  * constants z_i): rows_a, rows_b [count][2d][n], the layout fhe_tggsw_prepare takes */
 int fhe_tggsw_encrypt(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, double std_dev,
                       const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+
+/* tglwe.rs:91-103 `Tglwe::sk_encrypt` at rank k: sk [k n] binary (the TLWE key that `as_rings` cuts into k rings, tglwe.rs:40-44);
+ * pt [rows][n] or NULL; ct [rows][k + 1][n] with b = sum_j a_j s_j + e + pt */
+int fhe_tglwek_sk_encrypt(const fhe_torus_ctx *t, int k, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, double std_dev,
+                          const fhe_rng *rng, uint64_t stream_id, uint64_t *ct, fhe_mem mem, void *stream);
+/* tggsw.rs:73-88 `Tggsw::sk_encrypt` at rank k of pt [count][n]: rows [count][(k + 1) d][k + 1][n], the layout fhe_tggswk_prepare takes */
+int fhe_tggswk_encrypt(const fhe_torus_ctx *t, int k, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count,
+                       double std_dev, const fhe_rng *rng, uint64_t stream_id, uint64_t *rows, fhe_mem mem, void *stream);
 
 #ifdef __cplusplus
 }

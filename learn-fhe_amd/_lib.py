@@ -161,6 +161,18 @@ def lib():
         L.fhe_rgsw_encrypt.argtypes = [vp, ci, ci, vp, vp, sz, sz, vp, C.c_uint64, vp, vp, ci, vp]
         L.fhe_rlwe_ksk_gen.argtypes = [vp, ci, ci, vp, vp, C.c_int64, sz, vp, C.c_uint64, vp, vp, ci, vp]
         L.fhe_tfhe_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+        # any TGLWE rank k (torusk_api.hip)
+        L.fhe_tggswk_prepare.argtypes = [vp, ci, ci, ci, vp, sz, sz, ci, C.POINTER(vp)]
+        L.fhe_tggswk_key_destroy.argtypes = [vp]
+        L.fhe_tggswk_key_destroy.restype = None
+        L.fhe_tggswk_external_product.argtypes = [vp, vp, sz, vp, sz, ci, vp]
+        L.fhe_tggswk_cmux.argtypes = [vp, vp, sz, vp, vp, vp, sz, ci, vp]
+        L.fhe_tglwek_rotate.argtypes = [vp, ci, sz, C.c_int64, vp, sz, ci, vp]
+        L.fhe_tglwek_sample_extract.argtypes = [vp, ci, sz, sz, vp, vp, sz, ci, vp]
+        L.fhe_tfhek_blind_rotate.argtypes = [vp, vp, vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_tfhek_bootstrap.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
+        L.fhe_tglwek_sk_encrypt.argtypes = [vp, ci, vp, vp, sz, sz, dbl, vp, u64, vp, ci, vp]
+        L.fhe_tggswk_encrypt.argtypes = [vp, ci, ci, ci, vp, vp, sz, sz, dbl, vp, u64, vp, ci, vp]
         _lib = L
     return _lib
 

@@ -604,6 +604,92 @@ class TggswKey:
         return out_a, out_b
 
 
+class TggswKeyK:
+    """Prepared TGGSW ciphertexts of any TGLWE rank k (scheme/tfhe/src/tggsw.rs:44-88; the reference's `TglweParam::n`).
+    rows [count][(k + 1) d][k + 1][n]; ciphertexts are single buffers [batch][k + 1][n] (a_0 .. a_{k-1}, b)."""
+
+    def __init__(self, t: TorusContext, k, log_b, d, rows, n):
+        self.t, self.k, self.log_b, self.d, self.n = t, k, log_b, d, n
+        pr, cnt, mem, _ = _buf(rows)
+        self.count = cnt // ((k + 1) * d * (k + 1) * n)
+        self._h = C.c_void_p()
+        L.check(L.lib().fhe_tggswk_prepare(t.handle, k, log_b, d, pr, n, self.count, mem, C.byref(self._h)), "fhe_tggswk_prepare")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and L is not None and getattr(L, "lib", None):
+            L.lib().fhe_tggswk_key_destroy(h)
+
+    def _batch(self, cnt):
+        return cnt // ((self.k + 1) * self.n)
+
+    def external_product_(self, index, ct):
+        """tggsw.rs:100-112, in place."""
+        pc, cnt, mem, st = _buf(ct)
+        L.check(L.lib().fhe_tggswk_external_product(self.t.handle, self._h, index, pc, self._batch(cnt), mem, st), "fhe_tggswk_external_product")
+
+    def cmux(self, index, ct0, ct1):
+        """tggsw.rs:114-121."""
+        p0, cnt, mem, st = _buf(ct0)
+        out = _like(ct0, (self._batch(cnt), self.k + 1, self.n))
+        L.check(L.lib().fhe_tggswk_cmux(self.t.handle, self._h, index, p0, _buf(ct1)[0], _buf(out)[0], self._batch(cnt), mem, st), "fhe_tggswk_cmux")
+        return out
+
+    def blind_rotate(self, a_tilde, b_tilde, v):
+        """bootstrapping.rs:84-96 -> [batch][k + 1][n]."""
+        pa, _, mem, st = _buf(a_tilde)
+        pb, batch, _, _ = _buf(b_tilde)
+        out = _like(a_tilde, (batch, self.k + 1, self.n))
+        L.check(L.lib().fhe_tfhek_blind_rotate(self.t.handle, self._h, pa, pb, _buf(v)[0], _buf(out)[0], batch, mem, st), "fhe_tfhek_blind_rotate")
+        return out
+
+    def bootstrap(self, ks_log_b, ks_d, ksk_a, ksk_b, v, lwe_a, lwe_b):
+        """bootstrapping.rs:78-82 in one call: lwe_a [batch][n_lwe], lwe_b [batch] -> (a [batch][n_lwe], b [batch])."""
+        pka, _, mem, st = _buf(ksk_a)
+        pb, batch, _, _ = _buf(lwe_b)
+        out_a, out_b = _like(lwe_a, (batch, self.count)), _like(lwe_a, (batch,))
+        L.check(L.lib().fhe_tfhek_bootstrap(self.t.handle, self._h, ks_log_b, ks_d, pka, _buf(ksk_b)[0], _buf(v)[0], _buf(lwe_a)[0], pb, _buf(out_a)[0],
+                                            _buf(out_b)[0], batch, mem, st), "fhe_tfhek_bootstrap")
+        return out_a, out_b
+
+
+def tglwek_rotate(ct, k, n, i):
+    """scheme/tfhe/src/tglwe.rs:61-66 for [batch][k + 1][n] ciphertexts."""
+    pc, cnt, mem, st = _buf(ct)
+    batch = cnt // ((k + 1) * n)
+    out = _like(ct, (batch, k + 1, n))
+    L.check(L.lib().fhe_tglwek_rotate(pc, k, n, int(i), _buf(out)[0], batch, mem, st), "fhe_tglwek_rotate")
+    return out
+
+
+def tglwek_sample_extract(ct, k, n, index):
+    """scheme/tfhe/src/tglwe.rs:115-127 -> (a [batch][k n], b [batch])."""
+    pc, cnt, mem, st = _buf(ct)
+    batch = cnt // ((k + 1) * n)
+    out_a, out_b = _like(ct, (batch, k * n)), _like(ct, (batch,))
+    L.check(L.lib().fhe_tglwek_sample_extract(pc, k, n, index, _buf(out_a)[0], _buf(out_b)[0], batch, mem, st), "fhe_tglwek_sample_extract")
+    return out_a, out_b
+
+
+def tglwek_sk_encrypt(t, k, sk, pt, n, rows, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tglwe.rs:91-103 at rank k: sk [k n] -> ct [rows][k + 1][n]"""
+    ps, _, mem, st = _buf(sk)
+    pp = _buf(pt)[0] if pt is not None else None
+    ct = _like(sk, (rows, k + 1, n))
+    L.check(L.lib().fhe_tglwek_sk_encrypt(t.handle, k, ps, pp, n, rows, std_dev, _rng(seed), stream_id, _buf(ct)[0], mem, st), "fhe_tglwek_sk_encrypt")
+    return ct
+
+
+def tggswk_encrypt(t, k, log_b, d, sk, pt, n, std_dev, seed, stream_id):
+    """scheme/tfhe/src/tggsw.rs:73-88 at rank k for pt [count][n] -> rows [count][(k + 1) d][k + 1][n]"""
+    ps, _, mem, st = _buf(sk)
+    pp, cnt, _, _ = _buf(pt)
+    count = cnt // n
+    rows = _like(sk, (count, (k + 1) * d, k + 1, n))
+    L.check(L.lib().fhe_tggswk_encrypt(t.handle, k, log_b, d, ps, pp, n, count, std_dev, _rng(seed), stream_id, _buf(rows)[0], mem, st), "fhe_tggswk_encrypt")
+    return rows
+
+
 def tglwe_sample_extract(ct_a, ct_b, n, index):
     pa, cnt, mem, st = _buf(ct_a)
     pb, _, _, _ = _buf(ct_b)

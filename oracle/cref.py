@@ -347,3 +347,49 @@ def tfhe_bootstrap(log_b, d, ks_log_b, ks_d, brk_a, brk_b, ksk_a, ksk_b, v, lwe_
                                   _p(lwe_b), _p(oa), _p(ob), C.c_size_t(n), C.c_size_t(batch), threads, int(fft))
     assert rc == 0
     return oa, ob
+
+
+# ---- row T at any TGLWE rank k: ciphertexts are [k + 1][n] buffers, TGGSW rows [(k + 1) d][k + 1][n] ----
+
+def tggswk_external_product(k, log_b, d, rows, ct):
+    rows, ct = _arr(rows), _arr(ct).copy()
+    n = ct.shape[-1]
+    assert ct.shape == (k + 1, n) and rows.shape == ((k + 1) * d, k + 1, n)
+    assert lib().ref_tggswk_external_product(k, log_b, d, _p(rows), _p(ct), C.c_size_t(n)) == 0
+    return ct
+
+
+def tggswk_cmux(k, log_b, d, rows, ct0, ct1):
+    rows, ct0, ct1 = _arr(rows), _arr(ct0), _arr(ct1)
+    out = np.zeros_like(ct0)
+    assert lib().ref_tggswk_cmux(k, log_b, d, _p(rows), _p(ct0), _p(ct1), _p(out), C.c_size_t(ct0.shape[-1])) == 0
+    return out
+
+
+def tfhek_blind_rotate(k, log_b, d, brk, v, a_tilde, b_tilde, threads=1):
+    """brk [n_lwe][(k+1)d][k+1][n]; a_tilde [batch][n_lwe]; b_tilde [batch] -> [batch][k+1][n]"""
+    brk, v, a_tilde, b_tilde = _arr(brk), _arr(v), _arr(a_tilde), _arr(b_tilde)
+    n, batch, n_lwe = v.size, b_tilde.size, brk.shape[0]
+    out = np.zeros((batch, k + 1, n), dtype=np.uint64)
+    rc = lib().ref_tfhek_blind_rotate(k, log_b, d, _p(brk), C.c_size_t(n_lwe), _p(v), _p(a_tilde), _p(b_tilde), _p(out), C.c_size_t(n),
+                                      C.c_size_t(batch), threads)
+    assert rc == 0
+    return out
+
+
+def tglwek_sample_extract(k, ct, i):
+    ct = _arr(ct)
+    n = ct.shape[-1]
+    la, lb = np.zeros(k * n, dtype=np.uint64), C.c_uint64()
+    lib().ref_tglwek_sample_extract(k, _p(ct), C.c_size_t(n), C.c_size_t(i), _p(la), C.byref(lb))
+    return la, lb.value
+
+
+def tfhek_bootstrap(k, log_b, d, ks_log_b, ks_d, brk, ksk_a, ksk_b, v, lwe_a, lwe_b, threads=1):
+    brk, ksk_a, ksk_b, v, lwe_a, lwe_b = map(_arr, (brk, ksk_a, ksk_b, v, lwe_a, lwe_b))
+    n, batch, n_lwe = v.size, lwe_b.size, brk.shape[0]
+    oa, ob = np.zeros((batch, n_lwe), dtype=np.uint64), np.zeros(batch, dtype=np.uint64)
+    rc = lib().ref_tfhek_bootstrap(k, log_b, d, ks_log_b, ks_d, _p(brk), _p(ksk_a), _p(ksk_b), C.c_size_t(n_lwe), _p(v), _p(lwe_a), _p(lwe_b),
+                                   _p(oa), _p(ob), C.c_size_t(n), C.c_size_t(batch), threads)
+    assert rc == 0
+    return oa, ob

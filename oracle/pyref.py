@@ -972,3 +972,71 @@ def tlwe_ksk_gen(dec, sk0, sk1, rng, noise=0):
 
 def tlwe_phase(sk, a, b):
     return (b - sum(x * s for x, s in zip(a, sk))) % M64
+
+
+# ---- row T at any TGLWE rank k (the reference's `TglweParam::n`; tglwe.rs / tggsw.rs are generic in it and test at k = 2) ----
+# a ciphertext is a list of k + 1 polynomials [a_0, .., a_{k-1}, b]; a TGGSW ciphertext a list of (k + 1) d of them
+
+def tglwek_sk_encrypt(k, s_bits, pt, rng, noise=0):
+    """scheme/tfhe/src/tglwe.rs:91-103: b = sum_j a_j * s_j + e + pt, the key cut into k rings (tglwe.rs:40-44 `as_rings`)."""
+    n = len(pt)
+    a = [[rng.getrandbits(64) for _ in range(n)] for _ in range(k)]
+    b = [(rng.randint(-noise, noise) if noise else 0) % M64 for _ in range(n)]
+    for j in range(k):
+        b = tpoly_add(b, torus_mul_exact(a[j], [x % M64 for x in s_bits[j * n:(j + 1) * n]]))
+    return a + [tpoly_add(b, pt)]
+
+
+def tglwek_phase(k, s_bits, ct):
+    """tglwe.rs:105-113 `decrypt` before rounding: b - sum_j a_j * s_j."""
+    n = len(ct[0])
+    mu = ct[k]
+    for j in range(k):
+        mu = tpoly_sub(mu, torus_mul_exact(ct[j], [x % M64 for x in s_bits[j * n:(j + 1) * n]]))
+    return mu
+
+
+def tggswk_sk_encrypt(k, dec, s_bits, pt, rng, noise=0):
+    """scheme/tfhe/src/tggsw.rs:73-88: (k + 1) d encryptions of zero; rows j d .. (j + 1) d get pt * base on a_j (j < k), the last d on b."""
+    n, d = len(pt), dec.d
+    pts = dec.power_up_poly(pt)
+    rows = [tglwek_sk_encrypt(k, s_bits, [0] * n, rng, noise) for _ in range((k + 1) * d)]
+    for col in range(k + 1):
+        for j in range(d):
+            rows[col * d + j][col] = tpoly_add(rows[col * d + j][col], pts[j])
+    return rows
+
+
+def tggswk_external_product(k, dec, rows, ct):
+    """scheme/tfhe/src/tggsw.rs:100-112: limbs = flat_map(decompose) over a_0 .. a_{k-1}, b; every output polynomial is the dot
+    product of that column of the rows with the limbs."""
+    limbs = [l for poly in ct for l in dec.decompose(poly)]
+    n = len(ct[0])
+    out = [[0] * n for _ in range(k + 1)]
+    for row, l in zip(rows, limbs):
+        for c in range(k + 1):
+            out[c] = tpoly_add(out[c], torus_mul_exact(row[c], l))
+    return out
+
+
+def tggswk_cmux(k, dec, rows, ct0, ct1):
+    """scheme/tfhe/src/tggsw.rs:114-121."""
+    ext = tggswk_external_product(k, dec, rows, [tpoly_sub(x, y) for x, y in zip(ct1, ct0)])
+    return [tpoly_add(x, y) for x, y in zip(ct0, ext)]
+
+
+def tfhek_blind_rotate(k, dec, brk, v_encoded, a_tilde, b_tilde):
+    """scheme/tfhe/src/bootstrapping.rs:84-96."""
+    n = len(v_encoded)
+    acc = [[0] * n for _ in range(k)] + [torus_monomial_mul(v_encoded, -b_tilde)]
+    for rows, ai in zip(brk, a_tilde):
+        acc = tggswk_cmux(k, dec, rows, acc, [torus_monomial_mul(p, ai) for p in acc])
+    return acc
+
+
+def tglwek_sample_extract(k, ct, i):
+    """scheme/tfhe/src/tglwe.rs:115-127."""
+    a = []
+    for j in range(k):
+        a += tglwe_sample_extract(ct[j], ct[k], i)[0]
+    return a, ct[k][i]

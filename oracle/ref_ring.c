@@ -824,6 +824,96 @@ int ref_tfhe_bootstrap(int log_b, int d, int ks_log_b, int ks_d, const u64 *brk_
     return 0;
 }
 
+/* ==== row T at any TGLWE rank k (the reference's `TglweParam::n`; its own TGLWE / TGGSW tests run at k = 2: tglwe.rs:138-166,
+ * tggsw.rs:134-181).  A ciphertext is one buffer [k + 1][n]: a_0 .. a_{k-1}, b (tglwe.rs:49-50); a TGGSW ciphertext is (k + 1) d of
+ * them, rows in the order tggsw.rs:80-87 builds.  Exact products only (the checker). ======================================== */
+/* tggsw.rs:100-112: limbs = flat_map(decompose) over a_0 .. a_{k-1}, b; out_c = sum_l rows[l][c] * limb_l.  In place on ct. */
+static void tggswk_ext_ws(int k, int log_b, int d, const u64 *rows, u64 *ct, size_t n, u64 *ws) {
+    const size_t k1 = (size_t)k + 1, R = k1 * d;
+    u64 *limbs = ws, *out = ws + R * n, *tmp = out + k1 * n;
+    for (size_t c = 0; c < k1; c++) ref_torus_decompose(log_b, d, ct + c * n, n, limbs + c * d * n);
+    memset(out, 0, k1 * n * sizeof(u64));
+    for (size_t l = 0; l < R; l++)
+        for (size_t c = 0; c < k1; c++) {
+            ref_torus_mul_exact(rows + (l * k1 + c) * n, limbs + l * n, tmp, n);
+            for (size_t i = 0; i < n; i++) out[c * n + i] += tmp[i];
+        }
+    memcpy(ct, out, k1 * n * sizeof(u64));
+}
+static size_t tggswk_ws_words(int k, int d, size_t n) { return ((size_t)(k + 1) * d + (size_t)k + 2) * n; }
+
+int ref_tggswk_external_product(int k, int log_b, int d, const u64 *rows, u64 *ct, size_t n) {
+    if (k < 1 || log_b < 1 || d < 1 || log_b * d > 64 + log_b - 1) return 1;
+    u64 *ws = malloc(tggswk_ws_words(k, d, n) * sizeof(u64));
+    tggswk_ext_ws(k, log_b, d, rows, ct, n, ws);
+    free(ws);
+    return 0;
+}
+
+/* tggsw.rs:114-121: out = ct0 + external_product(rows, ct1 - ct0) */
+int ref_tggswk_cmux(int k, int log_b, int d, const u64 *rows, const u64 *ct0, const u64 *ct1, u64 *out, size_t n) {
+    const size_t w = ((size_t)k + 1) * n;
+    u64 *diff = malloc(w * sizeof(u64));
+    for (size_t i = 0; i < w; i++) diff[i] = ct1[i] - ct0[i];
+    const int rc = ref_tggswk_external_product(k, log_b, d, rows, diff, n);
+    for (size_t i = 0; i < w && !rc; i++) out[i] = ct0[i] + diff[i];
+    free(diff);
+    return rc;
+}
+
+/* bootstrapping.rs:84-96: acc = (0, .., 0, v).rotate(-b); fold cmux(brk_i, acc, acc.rotate(a_i)).  brk [n_lwe][(k+1)d][k+1][n],
+ * a_tilde [batch][n_lwe] (mod-switched), out [batch][k+1][n] */
+int ref_tfhek_blind_rotate(int k, int log_b, int d, const u64 *brk, size_t n_lwe, const u64 *v, const u64 *a_tilde, const u64 *b_tilde, u64 *out,
+                           size_t n, size_t batch, int threads) {
+    const size_t k1 = (size_t)k + 1, w = k1 * n, per = k1 * d * w;
+    (void)threads;
+#pragma omp parallel for schedule(dynamic) num_threads(threads > 0 ? threads : 1)
+    for (size_t c = 0; c < batch; c++) {
+        u64 *ws = malloc((tggswk_ws_words(k, d, n) + 2 * w) * sizeof(u64));
+        u64 *acc = ws, *diff = ws + w, *ext = ws + 2 * w;
+        memset(acc, 0, w * sizeof(u64));
+        ref_torus_monomial_mul(-(int64_t)b_tilde[c], v, acc + (size_t)k * n, n);
+        for (size_t i = 0; i < n_lwe; i++) {
+            const int64_t ai = (int64_t)a_tilde[c * n_lwe + i];
+            for (size_t j = 0; j < k1; j++) ref_torus_monomial_mul(ai, acc + j * n, diff + j * n, n);
+            for (size_t x = 0; x < w; x++) diff[x] -= acc[x];
+            tggswk_ext_ws(k, log_b, d, brk + i * per, diff, n, ext);
+            for (size_t x = 0; x < w; x++) acc[x] += diff[x];
+        }
+        memcpy(out + c * w, acc, w * sizeof(u64));
+        free(ws);
+    }
+    return 0;
+}
+
+/* tglwe.rs:115-127: lwe_a [k n] = concat_j (a_j[..=i].rev() ++ a_j[i+1..].rev().neg()), lwe_b = b[i] */
+void ref_tglwek_sample_extract(int k, const u64 *ct, size_t n, size_t i, u64 *lwe_a, u64 *lwe_b) {
+    for (int j = 0; j < k; j++) {
+        u64 dummy;
+        ref_tglwe_sample_extract(ct + (size_t)j * n, ct + (size_t)k * n, n, i, lwe_a + (size_t)j * n, &dummy);
+    }
+    *lwe_b = ct[(size_t)k * n + i];
+}
+
+/* bootstrapping.rs:78-82 at rank k: the key switch takes the TLWE of dimension k n (ksk_a [k n ks_d][n_lwe]) */
+int ref_tfhek_bootstrap(int k, int log_b, int d, int ks_log_b, int ks_d, const u64 *brk, const u64 *ksk_a, const u64 *ksk_b, size_t n_lwe, const u64 *v,
+                        const u64 *lwe_a, const u64 *lwe_b, u64 *out_a, u64 *out_b, size_t n, size_t batch, int threads) {
+    const size_t w = ((size_t)k + 1) * n;
+    u64 *at = malloc(batch * n_lwe * sizeof(u64)), *bt = malloc(batch * sizeof(u64)), *acc = malloc(batch * w * sizeof(u64));
+    ref_tfhe_mod_switch(lwe_a, at, batch * n_lwe, n);
+    ref_tfhe_mod_switch(lwe_b, bt, batch, n);
+    ref_tfhek_blind_rotate(k, log_b, d, brk, n_lwe, v, at, bt, acc, n, batch, threads);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1)
+    for (size_t c = 0; c < batch; c++) {
+        u64 *ea = malloc((size_t)k * n * sizeof(u64)), eb;
+        ref_tglwek_sample_extract(k, acc + c * w, n, 0, ea, &eb);
+        ref_tlwe_key_switch(ks_log_b, ks_d, ksk_a, ksk_b, ea, eb, (size_t)k * n, n_lwe, out_a + c * n_lwe, out_b + c);
+        free(ea);
+    }
+    free(at); free(bt); free(acc);
+    return 0;
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -132,3 +132,76 @@ def test_reference_f64_product_is_within_its_own_bound_of_the_exact_one():
         a = rng.integers(-(1 << 15), 1 << 15, size=n, dtype=np.int64).view(np.uint64)
         b = rng.integers(-(1 << 15), 1 << 15, size=n, dtype=np.int64).view(np.uint64)
         assert np.array_equal(cref.torus_mul_fft64(a, b), cref.torus_mul_exact(a, b))
+
+
+# ---- any TGLWE rank k: the reference's own TGLWE / TGGSW tests run at k = 2 (tglwe.rs:138-166, tggsw.rs:134-181) ----
+
+def _negacyclic_mod(a, b, p):
+    n = len(a)
+    c = [0] * n
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            if i + j < n:
+                c[i + j] += x * y
+            else:
+                c[i + j - n] -= x * y
+    return [v % p for v in c]
+
+
+def test_rank2_reference_tests_decode_level_on_the_oracle():
+    """tglwe.rs:138-166 `encrypt_decrypt`, `sample_extract`; tggsw.rs:150-181 `external_product`, `cmux`: (log_p, padding, big_n, n)
+    = (8, 1, N, 2), base 2^8, d = 8 -- at a smaller ring so that pure Python finishes, small integer noise in place of tdg(1e-8)"""
+    rnd = random.Random(77)
+    k, n, log_p, padding = 2, 32, 8, 1
+    dec = P.TorusDecomposor(8, 8)
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    s = [rnd.randint(0, 1) for _ in range(k * n)]
+    enc = lambda m: [(x << log_delta) % P.M64 for x in m]  # noqa: E731  tlwe.rs `encode`
+    dec_msg = lambda mu: [(((x + (1 << (log_delta - 1))) % P.M64) >> log_delta) % p for x in mu]  # noqa: E731  tlwe.rs `decode` of `round`
+    for _ in range(3):
+        m0, m1 = [rnd.randrange(p) for _ in range(n)], [rnd.randrange(p) for _ in range(n)]
+        ct1 = P.tglwek_sk_encrypt(k, s, enc(m1), rnd, noise=1 << 20)
+        assert dec_msg(P.tglwek_phase(k, s, ct1)) == m1
+        for i in (0, 1, n - 1):
+            la, lb = P.tglwek_sample_extract(k, ct1, i)
+            assert dec_msg([P.tlwe_phase(s, la, lb)])[0] == m1[i]
+        gg = P.tggswk_sk_encrypt(k, dec, s, m0, rnd, noise=1 << 20)  # Tggsw::encode: the message itself
+        assert dec_msg(P.tglwek_phase(k, s, P.tggswk_external_product(k, dec, gg, ct1))) == _negacyclic_mod(m0, m1, p)
+        ct0 = P.tglwek_sk_encrypt(k, s, enc(m0), rnd, noise=1 << 20)
+        for bit, want in ((0, m0), (1, m1)):
+            sel = P.tggswk_sk_encrypt(k, dec, s, [bit] + [0] * (n - 1), rnd, noise=1 << 20)
+            assert dec_msg(P.tglwek_phase(k, s, P.tggswk_cmux(k, dec, sel, ct0, ct1))) == want
+
+
+def test_c_oracle_rank_k_matches_python_oracle():
+    import numpy as np
+    from oracle import cref
+    rnd = random.Random(41)
+    U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+    for k, n, log_b, d, n_lwe in [(1, 16, 10, 2, 3), (2, 16, 8, 8, 3), (3, 8, 7, 3, 2)]:
+        dec = P.TorusDecomposor(log_b, d)
+        k1 = k + 1
+        brk = [[[[rnd.getrandbits(64) for _ in range(n)] for _ in range(k1)] for _ in range(k1 * d)] for _ in range(n_lwe)]
+        ct0 = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(k1)]
+        ct1 = [[rnd.getrandbits(64) for _ in range(n)] for _ in range(k1)]
+        assert cref.tggswk_external_product(k, log_b, d, U(brk[0]), U(ct0)).tolist() == P.tggswk_external_product(k, dec, brk[0], ct0)
+        assert cref.tggswk_cmux(k, log_b, d, U(brk[1]), U(ct0), U(ct1)).tolist() == P.tggswk_cmux(k, dec, brk[1], ct0, ct1)
+        if k == 1:  # the rank-1 case is the k = 1 oracle in the other layout
+            ea, eb = P.tggsw_external_product(dec, [r[0] for r in brk[0]], [r[1] for r in brk[0]], ct0[0], ct0[1])
+            assert [ea, eb] == P.tggswk_external_product(k, dec, brk[0], ct0)
+        v = [rnd.getrandbits(64) for _ in range(n)]
+        a_raw, b_raw = [[rnd.getrandbits(64) for _ in range(n_lwe)] for _ in range(2)], [rnd.getrandbits(64) for _ in range(2)]
+        at, bt = cref.tfhe_mod_switch(U(a_raw), n), cref.tfhe_mod_switch(U(b_raw), n)
+        acc = cref.tfhek_blind_rotate(k, log_b, d, U(brk), U(v), at, bt, threads=2)
+        ksa = [[rnd.getrandbits(64) for _ in range(n_lwe)] for _ in range(k * n * 5)]
+        ksb = [rnd.getrandbits(64) for _ in range(k * n * 5)]
+        ga, gb = cref.tfhek_bootstrap(k, log_b, d, 4, 5, U(brk), U(ksa), U(ksb), U(v), U(a_raw), U(b_raw), threads=2)
+        for c in range(2):
+            want = P.tfhek_blind_rotate(k, dec, brk, v, [int(x) for x in at[c]], int(bt[c]))
+            assert acc[c].tolist() == want
+            for i in (0, n - 1, 5):
+                la, lb = cref.tglwek_sample_extract(k, acc[c], i)
+                assert (la.tolist(), lb) == P.tglwek_sample_extract(k, want, i)
+            xa, xb = P.tglwek_sample_extract(k, want, 0)
+            ya, yb = P.tlwe_key_switch(P.TorusDecomposor(4, 5), ksa, ksb, xa, xb)
+            assert (ga[c].tolist(), int(gb[c])) == (ya, yb)

@@ -1,0 +1,211 @@
+"""GPU parity tests for SURVEY.md section 8(a) row T at ANY TGLWE rank k (the reference's `TglweParam::n`) through the C ABI.
+The reference's TGLWE / TGGSW code is generic in the rank and its own tests of both run at k = 2, N = 256, base 2^8, d = 8
+(scheme/tfhe/src/tglwe.rs:138-166, tggsw.rs:134-181): those tests are repeated here at decode level on device-made keys, and every
+entry is compared bit for bit with the exact oracle (oracle/ref_ring.c `ref_tggswk_*`, pinned against oracle/pyref.py in
+tests/test_torus_cpu.py).  k = 1 through the rank-k entries must equal the fused k = 1 entries."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = lambda x: [int(v) for v in np.asarray(x).ravel()]  # noqa: E731
+U = lambda x: np.array(x, dtype=np.uint64)  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def r64(rng, *s):
+    return rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("k,log_n,log_b,d", [(2, 8, 8, 8), (1, 10, 7, 3), (3, 6, 10, 2), (2, 11, 23, 1), (4, 3, 16, 4), (1, 1, 4, 5)])
+def test_rank_k_entries_vs_oracle(fhe, cref, torch_cuda, k, log_n, log_b, d):
+    """external product (tggsw.rs:100-112), cmux (114-121), rotate (tglwe.rs:61-66), sample_extract (115-127): bit-equal to the exact
+    oracle; device and host memory; extreme key words and digits."""
+    n, batch, k1 = 1 << log_n, 3, k + 1
+    rng = np.random.Generator(np.random.PCG64(1000 * k + log_n))
+    rows = r64(rng, 2, k1 * d, k1, n)
+    rows[0, 0] = np.uint64(1 << 63)                      # the most negative key words
+    ct0, ct1 = r64(rng, batch, k1, n), r64(rng, batch, k1, n)
+    half = 1 << (log_b - 1)
+    ct0[0, :, : max(n // 2, 1)] = np.uint64((-sum(half << (64 - log_b * (j + 1)) for j in range(d) if 64 - log_b * (j + 1) >= 0)) % (1 << 64))
+    t = fhe.TorusContext()
+    key = fhe.TggswKeyK(t, k, log_b, d, dev(torch_cuda, rows), n)
+    x = dev(torch_cuda, ct0)
+    key.external_product_(1, x)
+    for i in range(batch):
+        assert np.array_equal(host(x)[i], cref.tggswk_external_product(k, log_b, d, rows[1], ct0[i])), i
+    hx = ct0.copy()                                      # FHE_MEM_HOST
+    fhe.TggswKeyK(t, k, log_b, d, rows, n).external_product_(0, hx)
+    for i in range(batch):
+        assert np.array_equal(hx[i], cref.tggswk_external_product(k, log_b, d, rows[0], ct0[i])), i
+    d0, d1 = dev(torch_cuda, ct0), dev(torch_cuda, ct1)
+    out = key.cmux(0, d0, d1)
+    for i in range(batch):
+        assert np.array_equal(host(out)[i], cref.tggswk_cmux(k, log_b, d, rows[0], ct0[i], ct1[i])), i
+    # out may alias either input
+    from learn_fhe_amd import _lib as LL
+    import ctypes as C
+    for alias in (0, 1):
+        a0, a1 = dev(torch_cuda, ct0), dev(torch_cuda, ct1)
+        tgt = a1 if alias else a0
+        st = C.c_void_p(torch_cuda.cuda.current_stream().cuda_stream)
+        LL.check(LL.lib().fhe_tggswk_cmux(t.handle, key._h, 0, C.c_void_p(a0.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(tgt.data_ptr()), batch,
+                                          LL.MEM_DEVICE, st), "fhe_tggswk_cmux")
+        assert torch_cuda.equal(tgt, out), alias
+    for r in (0, 1, n - 1, n, n + 1, 2 * n - 1, -1, -n - 3, 7 * n + 2):
+        xr = host(fhe.tglwek_rotate(d0, k, n, r))
+        for i in range(batch):
+            for j in range(k1):
+                assert np.array_equal(xr[i, j], cref.torus_monomial_mul(ct0[i, j], r)), (r, i, j)
+    for idx in sorted({0, 1 % n, n // 2, n - 1}):
+        ea, eb = fhe.tglwek_sample_extract(d1, k, n, idx)
+        for i in range(batch):
+            wa, wb = cref.tglwek_sample_extract(k, ct1[i], idx)
+            assert np.array_equal(host(ea)[i], wa) and int(host(eb)[i]) == wb, (idx, i)
+    if k == 1 and log_n >= 8:  # the fused k = 1 entries give the same bits
+        k1key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, np.ascontiguousarray(rows[:, :, 0])), dev(torch_cuda, np.ascontiguousarray(rows[:, :, 1])), n)
+        xa, xb = dev(torch_cuda, np.ascontiguousarray(ct0[:, 0])), dev(torch_cuda, np.ascontiguousarray(ct0[:, 1]))
+        k1key.external_product_(1, xa, xb)
+        assert np.array_equal(host(xa), host(x)[:, 0]) and np.array_equal(host(xb), host(x)[:, 1])
+
+
+@pytest.mark.parametrize("k,log_n,log_b,d,n_lwe,batch", [(2, 8, 8, 8, 6, 5), (1, 10, 7, 3, 5, 3), (3, 5, 12, 3, 9, 4)])
+def test_rank_k_blind_rotation_and_gate_vs_oracle(fhe, cref, torch_cuda, k, log_n, log_b, d, n_lwe, batch):
+    """bootstrapping.rs:84-96 and 78-82 at rank k on random keys: accumulators, and the whole gate (mod switch -> blind rotation ->
+    sample_extract(0) -> key switch from dimension k n), bit-equal to the exact oracle."""
+    n, k1 = 1 << log_n, k + 1
+    rng = np.random.Generator(np.random.PCG64(2000 * k + log_n))
+    brk, v = r64(rng, n_lwe, k1 * d, k1, n), r64(rng, n)
+    a_raw, b_raw = r64(rng, batch, n_lwe), r64(rng, batch)
+    a_raw[0, 0] = 0
+    t = fhe.TorusContext()
+    key = fhe.TggswKeyK(t, k, log_b, d, dev(torch_cuda, brk), n)
+    at, bt = cref.tfhe_mod_switch(a_raw, n), cref.tfhe_mod_switch(b_raw, n)
+    acc = key.blind_rotate(dev(torch_cuda, at), dev(torch_cuda, bt), dev(torch_cuda, v))
+    assert np.array_equal(host(acc), cref.tfhek_blind_rotate(k, log_b, d, brk, v, at, bt, threads=8))
+    ks_lb, ks_d = 4, 5
+    ksa, ksb = r64(rng, k * n * ks_d, n_lwe), r64(rng, k * n * ks_d)
+    oa, ob = key.bootstrap(ks_lb, ks_d, dev(torch_cuda, ksa), dev(torch_cuda, ksb), dev(torch_cuda, v), dev(torch_cuda, a_raw), dev(torch_cuda, b_raw))
+    ga, gb = cref.tfhek_bootstrap(k, log_b, d, ks_lb, ks_d, brk, ksa, ksb, v, a_raw, b_raw, threads=8)
+    assert np.array_equal(host(oa), ga) and np.array_equal(host(ob), gb)
+    if k == 1:  # the fused k = 1 blind rotation gives the same accumulators
+        k1key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, np.ascontiguousarray(brk[:, :, 0])), dev(torch_cuda, np.ascontiguousarray(brk[:, :, 1])), n)
+        fa, fb = k1key.blind_rotate(dev(torch_cuda, at), dev(torch_cuda, bt), dev(torch_cuda, v))
+        assert np.array_equal(host(fa).reshape(batch, n), host(acc)[:, 0]) and np.array_equal(host(fb).reshape(batch, n), host(acc)[:, 1])
+
+
+def _negacyclic_mod(a, b, p):
+    n = len(a)
+    full = np.convolve(np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64))
+    c = full[:n].copy()
+    c[: n - 1] -= full[n:]
+    return c % p
+
+
+def test_reference_rank2_tests_decode_level_on_device_made_keys(fhe, cref, torch_cuda):
+    """The reference's own tests at ITS parameters -- (log_p, padding, big_n, n, std_dev, log_b, d) = (8, 1, 256, 2, 1e-8, 8, 8):
+    tglwe.rs:138-150 `encrypt_decrypt`, 152-166 `sample_extract` (every index), tggsw.rs:136-148 `encrypt_decrypt` (decrypt of the last
+    row, rounding_shr by the last base), 150-165 `external_product`, 167-181 `cmux` -- with every key and ciphertext made by the device
+    producers (`Tglwe::sk_gen` = binary TLWE key of dimension k N, tglwe.rs:75-77)."""
+    k, n, log_p, padding, sd, log_b, d = 2, 256, 8, 1, 1.0e-8, 8, 8
+    p, log_delta, k1, rounds = 1 << log_p, 64 - (log_p + padding), k + 1, 12
+    like = dev(torch_cuda, U([0]))
+    t = fhe.TorusContext()
+    s = fhe.sample_binary(900, 0, like, k * n)
+    sh = host(s)
+    assert set(L(sh)) == {0, 1}
+    rng = np.random.Generator(np.random.PCG64(9))
+    m0, m1 = rng.integers(0, p, size=(rounds, n), dtype=np.uint64), rng.integers(0, p, size=(rounds, n), dtype=np.uint64)
+
+    def phase(ct):  # tglwe.rs:105-113: b - sum_j a_j s_j
+        mu = ct[k].copy()
+        for j in range(k):
+            mu -= cref.torus_mul_exact(ct[j], sh[j * n:(j + 1) * n])
+        return mu
+
+    def decode(mu):  # tlwe.rs `round(log_delta)` then `decode`
+        return ((mu + np.uint64(1 << (log_delta - 1))) >> np.uint64(log_delta)) % np.uint64(p)
+
+    ct0 = fhe.tglwek_sk_encrypt(t, k, s, dev(torch_cuda, m0 << np.uint64(log_delta)), n, rounds, sd, 901, 0)
+    ct1 = fhe.tglwek_sk_encrypt(t, k, s, dev(torch_cuda, m1 << np.uint64(log_delta)), n, rounds, sd, 901, 1)
+    h0, h1 = host(ct0), host(ct1)
+    assert not np.array_equal(h0[:, :k], h1[:, :k])                          # another stream id: another mask
+    for r in range(rounds):                                                   # tglwe.rs `encrypt_decrypt`
+        assert np.array_equal(decode(phase(h0[r])), m0[r]) and np.array_equal(decode(phase(h1[r])), m1[r])
+        noise = (phase(h0[r]) - (m0[r] << np.uint64(log_delta))).view(np.int64).astype(np.float64) / 2.0 ** 64
+        assert abs(noise).max() < 6 * sd and noise.std() > 0.5 * sd
+    for i in range(n):                                                        # tglwe.rs `sample_extract`, all indices, batch = rounds
+        la, lb = fhe.tglwek_sample_extract(ct1, k, n, i)
+        la, lb = host(la), host(lb)
+        ph = lb - (la * sh[None, :]).sum(axis=1, dtype=np.uint64)             # tlwe.rs:134-142
+        assert np.array_equal(decode(ph), m1[:, i]), i
+    gg = fhe.tggswk_encrypt(t, k, log_b, d, s, dev(torch_cuda, m0), n, sd, 902, 0)   # Tggsw::encode: the message itself (tggsw.rs:62-66)
+    hg = host(gg)
+    assert hg.shape == (rounds, k1 * d, k1, n)
+    for r in range(3):                                                        # tggsw.rs `encrypt_decrypt`: last row, shifted by the last base
+        mu = phase(hg[r, -1])
+        sh_bits = 64 - log_b                                                  # log_bases().last() = rounding_bits + (d - 1) log_b
+        assert np.array_equal(((mu + np.uint64(1 << (sh_bits - 1))) >> np.uint64(sh_bits)) % np.uint64(p), m0[r])
+    key = fhe.TggswKeyK(t, k, log_b, d, gg, n)
+    for r in range(rounds):                                                   # tggsw.rs `external_product`: decrypts to m0 * m1
+        x = ct1[r:r + 1].clone()
+        key.external_product_(r, x)
+        assert np.array_equal(decode(phase(host(x)[0])), _negacyclic_mod(m0[r], m1[r], p).astype(np.uint64)), r
+        assert np.array_equal(host(x)[0], cref.tggswk_external_product(k, log_b, d, hg[r], h1[r]))
+    bits = np.zeros((2, n), dtype=np.uint64)
+    bits[1, 0] = 1                                                            # Rq::constant(b)
+    sel = fhe.TggswKeyK(t, k, log_b, d, fhe.tggswk_encrypt(t, k, log_b, d, s, dev(torch_cuda, bits), n, sd, 903, 0), n)
+    for b, want in ((0, m0), (1, m1)):                                        # tggsw.rs `cmux`
+        out = host(sel.cmux(b, ct0, ct1))
+        for r in range(rounds):
+            assert np.array_equal(decode(phase(out[r])), want[r]), (b, r)
+
+
+def test_rank2_gate_bootstrap_decode_level(fhe, torch_cuda):
+    """`Bootstrapping::bootstrap` (bootstrapping.rs:78-82, test 139-165) with a rank-2 accumulator: big_n = 512, k = 2 (a TLWE of
+    dimension 1024 after sample_extract), n_lwe = 256, base 2^7 x 3, key switch (4, 5), log_p 3, padding 1; keys from the device
+    producers (`key_gen`, bootstrapping.rs:59-76: brk_i = TGGSW(z_i) under s, ksk = Tlwe::ksk_gen(z, s)); LUTs identity / double /
+    parity over all messages, decoded on the host."""
+    from oracle import pyref as P
+    k, n, n_lwe, log_p, padding, log_b, d, ks_lb, ks_d = 2, 512, 256, 3, 1, 7, 3, 4, 5
+    sd_lwe, sd_glwe = 2.0 ** -22, 2.0 ** -40
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    like = dev(torch_cuda, U([0]))
+    t = fhe.TorusContext()
+    z, s = fhe.sample_binary(910, 0, like, n_lwe), fhe.sample_binary(910, 1, like, k * n)
+    zh = L(host(z))
+    pt = np.zeros((n_lwe, n), dtype=np.uint64)
+    pt[:, 0] = host(z)
+    key = fhe.TggswKeyK(t, k, log_b, d, fhe.tggswk_encrypt(t, k, log_b, d, s, dev(torch_cuda, pt), n, sd_glwe, 911, 0), n)
+    ksa, ksb = fhe.tlwe_ksk_gen(ks_lb, ks_d, z, s, sd_lwe, 912, 0)
+
+    def table(f):
+        m_ = n >> log_p
+        tt = [f(v) % p for v in range(p)]
+        out = [tt[0]] * (m_ // 2)
+        for x in tt[1:]:
+            out += [x] * m_
+        return out + [(-tt[0]) % p] * (m_ // 2)
+
+    for li, f in enumerate((lambda v: v, lambda v: 2 * v, lambda v: v % 2)):
+        v = dev(torch_cuda, U([(x << log_delta) % P.M64 for x in table(f)]))
+        msgs = dev(torch_cuda, U([(m << log_delta) % P.M64 for m in range(p)]))
+        ca, cb = fhe.tlwe_sk_encrypt(z, msgs, n_lwe, p, sd_lwe, 913, li)
+        oa, ob = key.bootstrap(ks_lb, ks_d, ksa, ksb, v, ca, cb)
+        for m in range(p):
+            mu = ((P.tlwe_phase(zh, L(host(oa)[m]), int(host(ob)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
+            assert mu % p == f(m) % p, (li, m, mu)
