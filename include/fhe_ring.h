@@ -411,6 +411,19 @@ int fhe_ckks_sk_encrypt(const fhe_rns_ctx *rns, int extended, const uint64_t *sk
 int fhe_ckks_ksk_gen(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *sk_prime, size_t n, const fhe_rng *rng, uint64_t stream_id,
                      uint64_t *ksk_b, uint64_t *ksk_a, fhe_mem mem, void *stream);
 
+/* ckks.rs:227-238 `Ckks::pk_encrypt` for `batch` plaintexts over qs: u <- zo(0.5), e0, e1 <- dg(3.2, 6) per ciphertext; a = pk.a u + e0,
+ * b = pk.b u + e1 + pt.  pk_b, pk_a [L][n]: ckks.rs:143-146 `pk_gen` = fhe_ckks_sk_encrypt with pt NULL.  pt [batch][L][n] or NULL. */
+int fhe_ckks_pk_encrypt(const fhe_rns_ctx *rns, const uint64_t *pk_b, const uint64_t *pk_a, const uint64_t *pt, size_t n, size_t batch,
+                        const fhe_rng *rng, uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream);
+/* ckks.rs:240-248 `Ckks::decrypt`: pt = b + a sk over qs; sk [n] i64; ct_b, ct_a, pt [batch][L][n]; pt may alias ct_b.  (A ciphertext on
+ * fewer limbs decrypts through an fhe_rns_ctx over that prefix of qs.) */
+int fhe_ckks_decrypt(const fhe_rns_ctx *rns, const uint64_t *sk, const uint64_t *ct_b, const uint64_t *ct_a, size_t n, size_t batch, uint64_t *pt,
+                     fhe_mem mem, void *stream);
+/* ckks.rs:250-253 `Ckks::mul_constant` after its `encode` (host-side F256 arithmetic, out of scope): (pt * b, pt * a).rescale().  pt
+ * [pt_batch][L][n] encoded plaintexts, pt_batch = 1 (one constant for the batch) or batch; ct [batch][L][n] -> out [batch][L-1][n]. */
+int fhe_ckks_mul_plain(const fhe_rns_ctx *rns, const uint64_t *pt, size_t pt_batch, const uint64_t *ct_b, const uint64_t *ct_a, uint64_t *out_b,
+                       uint64_t *out_a, size_t n, size_t batch, fhe_mem mem, void *stream);
+
 /* ---- TFHE key material, k = 1 (rank k: fhe_tglwek_sk_encrypt / fhe_tggswk_encrypt at the end).  Draws are counter based (ChaCha20, as above): reproducible per
  * (generator key, stream_id), checked at decode level like the reference's own tests (its draws are unseeded). */
 /* util/src/misc/distribution.rs:49-54 `tdg(std_dev)`: torus Gaussian noise (Box-Muller deviate, fractional part scaled by 2^64) */

@@ -44,7 +44,7 @@ __host__ __device__ inline void chacha20_block(const ChaChaKey &K, unsigned long
 enum RngPurpose : unsigned {
     RNG_SAMPLE_UNIFORM = 1, RNG_SAMPLE_TORUS, RNG_SAMPLE_DG, RNG_SAMPLE_ZO, RNG_SAMPLE_TDG, RNG_SAMPLE_BINARY,
     RNG_RLWE_ENC, RNG_RGSW_ENC, RNG_RLWE_KSK, RNG_LWE_ENC, RNG_LWE_KSK, RNG_CKKS_ENC, RNG_CKKS_KSK,
-    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC
+    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC, RNG_CKKS_PK_ENC
 };
 }  // namespace fhe
 
@@ -198,29 +198,33 @@ FHE_HEADER_KERNEL void sample_zo_kernel(u64 *__restrict__ out, size_t count, dou
 
 // util/src/ring/rns.rs:61-63 `RnsRq::from_i64`: out[l][i] = v[i] mod m_l (zq.rs:63-69), v two's-complement i64, times mult[l] if given
 FHE_HEADER_KERNEL void rns_from_i64_kernel(const u64 *__restrict__ v, u64 *__restrict__ out, size_t n, int limbs, const Barrett *__restrict__ B,
-                                           const u64 *__restrict__ mult) {
-    const size_t total = n * limbs;
+                                           const u64 *__restrict__ mult, size_t polys = 1) {
+    const size_t total = n * limbs * polys;  // v [polys][n] -> out [polys][limbs][n]
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
-        const size_t l = idx / n, i = idx - l * n;
+        const size_t i = idx % n, l = (idx / n) % limbs, c = idx / (n * limbs);
         const Barrett b = B[l];
-        const long long x = (long long)v[i];
+        const long long x = (long long)v[c * n + i];
         u64 r = x < 0 ? (u64)(-x) % b.q : (u64)x % b.q;
         if (x < 0 && r) r = b.q - r;
         out[idx] = mult ? mulmod_barrett(r, mult[l], b) : r;
     }
 }
-// scheme/ckks/src/ckks.rs:222: b <- -(a s) + e + pt over [batch][limbs][n]; e [batch][n] i64; pt [batch or 1][limbs][n] or null
+// x <- (negate ? -x : x) + e + add over [batch][limbs][n]; e [batch][n] i64 or null; add [add_batch or 1][limbs][n] or null.
+// ckks.rs:222 `sk_encrypt` (b = -(a s) + e + pt: negate), 235-236 `pk_encrypt` (pk u + e (+ pt)), 246 `decrypt` (a s + b)
 FHE_HEADER_KERNEL void ckks_finish_b_kernel(u64 *__restrict__ b, const u64 *__restrict__ e, const u64 *__restrict__ pt, size_t n, int limbs, size_t batch,
-                                            size_t pt_batch, const Barrett *__restrict__ B) {
+                                            size_t pt_batch, const Barrett *__restrict__ B, int negate) {
     const size_t total = batch * limbs * n;
     for (size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * blockDim.x) {
         const size_t i = idx % n, l = (idx / n) % limbs, c = idx / (n * limbs);
         const u64 q = B[l].q;
-        const long long x = (long long)e[c * n + i];
-        u64 ev = x < 0 ? (u64)(-x) % q : (u64)x % q;
-        if (x < 0 && ev) ev = q - ev;
+        u64 ev = 0;
+        if (e) {
+            const long long x = (long long)e[c * n + i];
+            ev = x < 0 ? (u64)(-x) % q : (u64)x % q;
+            if (x < 0 && ev) ev = q - ev;
+        }
         const u64 as = b[idx];
-        u64 r = csub((as ? q - as : 0) + ev, q);
+        u64 r = csub((negate ? (as ? q - as : 0) : as) + ev, q);
         if (pt) r = csub(r + pt[((c % pt_batch) * limbs + l) * n + i], q);
         b[idx] = r;
     }

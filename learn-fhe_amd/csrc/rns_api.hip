@@ -954,10 +954,24 @@ int ckks_sk_encrypt_dev(const fhe_rns_ctx *r, int limbs, const u64 *sk, const u6
     }
     if (rc == FHE_OK) {
         hipLaunchKernelGGL(fhe::ckks_finish_b_kernel, dim3(grid_for(batch * limbs * n)), dim3(256), 0, st, out_b, (const u64 *)e, pt, n, limbs, batch,
-                           pt ? pt_batch : 1, (const fhe::Barrett *)r->d_barrett);
+                           pt ? pt_batch : 1, (const fhe::Barrett *)r->d_barrett, 1);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     return rc;
+}
+
+// forward transforms of two caller buffers ([polys][n] each, polys a multiple of L) out of place into dst [2][polys][n]: one launch
+// where the kernels take grouped sources (NttIo::src_group), two otherwise
+int fwd_two_sources(const fhe_rns_ctx *r, const u64 *a, const u64 *b, u64 *dst, int log_n, size_t polys, hipStream_t st) {
+    fhe::NttIo io;
+    if (log_n >= 1 && log_n <= 15 && polys < (size_t(1) << 30)) {
+        io.src = a; io.src2 = b; io.src_group = (unsigned)polys;
+        return fhe::ntt_fwd_multi(r->d_descs, (unsigned)r->L, dst, log_n, 2 * polys, st, r->all_pm, io);
+    }
+    io.src = a; io.src_mod = (unsigned)polys;
+    int rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)r->L, dst, log_n, polys, st, r->all_pm, io);
+    io.src = b;
+    return rc != FHE_OK ? rc : fhe::ntt_fwd_multi(r->d_descs, (unsigned)r->L, dst + (polys << log_n), log_n, polys, st, r->all_pm, io);
 }
 
 int ckks_ring_ok(const fhe_rns_ctx *r, size_t n) {
@@ -1072,6 +1086,140 @@ int fhe_ckks_ksk_gen(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *s
     if (rc == FHE_OK) rc = mb.sync_out(st);
     if (rc == FHE_OK) rc = ma.sync_out(st);
     return rc;
+}
+
+// scheme/ckks/src/ckks.rs:240-248 `Ckks::decrypt`: pt = b + a * sk over qs.  sk [n] i64; ct_b, ct_a, pt [batch][L][n] (coefficient
+// domain); pt may alias ct_b
+int fhe_ckks_decrypt(const fhe_rns_ctx *r, const uint64_t *sk, const uint64_t *ct_b, const uint64_t *ct_a, size_t n, size_t batch, uint64_t *pt, fhe_mem mem,
+                     void *stream) {
+    int rc = ckks_ring_ok(r, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || ((!ct_b || !ct_a || !pt) && batch) || (batch && pt == ct_a)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int L = r->L, log_n = ilog2(n);
+    const size_t words = batch * L * n;
+    if (batch * L >= (size_t(1) << 31)) return FHE_ERR_UNSUPPORTED;
+    Mirror msk(sk, n, mem, true, st), mb(ct_b, words, mem, true, st), ma(ct_a, words, mem, true, st), mo(pt, words, mem, false, st);
+    if (msk.rc | mb.rc | ma.rc | mo.rc) return FHE_ERR_HIP;
+    StreamWs ws((size_t(L) * n + words) * sizeof(u64), st);  // the key's evaluations | a s
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *s_eval = ws.as<u64>(), *as = s_eval + size_t(L) * n;
+    hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(n * L)), dim3(256), 0, st, (const u64 *)msk.d, s_eval, n, L, (const fhe::Barrett *)r->d_barrett,
+                       (const u64 *)nullptr, (size_t)1);
+    HIP_TRY(hipGetLastError());
+    rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, s_eval, log_n, L, st, r->all_pm);
+    if (rc == FHE_OK) {
+        fhe::NttIo src;
+        src.src = ma.d; src.src_mod = (unsigned)(batch * L);
+        rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, as, log_n, batch * L, st, r->all_pm, src);
+    }
+    if (rc == FHE_OK) {
+        fhe::NttIo mul;
+        mul.mul = s_eval; mul.mul_div = (unsigned)(batch * L); mul.mul_period = (unsigned)L;
+        rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)L, as, log_n, batch * L, st, r->all_pm, mul);
+    }
+    if (rc != FHE_OK) return rc;
+    // pt = a s + b: formed in the scratch, then moved (pt may be ct_b itself)
+    hipLaunchKernelGGL(fhe::ckks_finish_b_kernel, dim3(grid_for(words)), dim3(256), 0, st, as, (const u64 *)nullptr, (const u64 *)mb.d, n, L, batch, batch,
+                       (const fhe::Barrett *)r->d_barrett, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mo.d, as, words * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    return mo.sync_out(st);
+}
+
+// scheme/ckks/src/ckks.rs:227-238 `Ckks::pk_encrypt` for `batch` plaintexts over qs: u <- zo(0.5), e0, e1 <- dg(3.2, 6) per ciphertext;
+// a = pk.a u + e0, b = pk.b u + e1 + pt.  pk_b, pk_a [L][n] (ckks.rs:143-146 `pk_gen` = fhe_ckks_sk_encrypt with pt NULL); pt
+// [batch][L][n] or NULL; out_b, out_a [batch][L][n]
+int fhe_ckks_pk_encrypt(const fhe_rns_ctx *r, const uint64_t *pk_b, const uint64_t *pk_a, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng,
+                        uint64_t stream_id, uint64_t *out_b, uint64_t *out_a, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    int rc = ckks_ring_ok(r, n);
+    if (rc != FHE_OK) return rc;
+    if (!pk_b || !pk_a || ((!out_b || !out_a) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int L = r->L, log_n = ilog2(n);
+    const size_t words = batch * L * n, kw = size_t(L) * n;
+    if (batch * L >= (size_t(1) << 31)) return FHE_ERR_UNSUPPORTED;
+    Mirror mpb(pk_b, kw, mem, true, st), mpa(pk_a, kw, mem, true, st), mpt(pt, pt ? words : 0, mem, true, st), mb(out_b, words, mem, false, st),
+        ma(out_a, words, mem, false, st);
+    if (mpb.rc | mpa.rc | mpt.rc | mb.rc | ma.rc) return FHE_ERR_HIP;
+    StreamWs ws((2 * kw + 3 * batch * n) * sizeof(u64), st);  // pk evaluations (b | a) | u | e0 | e1 as i64
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *pk_eval = ws.as<u64>(), *u = pk_eval + 2 * kw, *e0 = u + batch * n, *e1 = e0 + batch * n;
+    const fhe::ChaChaKey K = fhe::call_key(rng, stream_id, fhe::RNG_CKKS_PK_ENC);
+    unsigned long long cursor = 0;
+    hipLaunchKernelGGL(fhe::sample_zo_kernel, dim3(grid_for((batch * n + 7) / 8)), dim3(256), 0, st, u, batch * n, 0.5, K, cursor);
+    cursor += (batch * n + 7) / 8;
+    HIP_TRY(hipGetLastError());
+    fhe::DgTable T;
+    if (!fhe::make_dg_table(3.2, 6, &T)) return FHE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fhe::sample_dg_kernel, dim3(grid_for((2 * batch * n + 7) / 8)), dim3(256), 0, st, e0, 2 * batch * n, (u64)0, T, K, cursor);  // e0 | e1
+    HIP_TRY(hipGetLastError());
+    rc = fwd_two_sources(r, mpb.d, mpa.d, pk_eval, log_n, L, st);  // pk.b, pk.a -> evaluation domain
+    // u over every limb into both outputs' buffers, forward, then the inverse transforms multiply by pk.b / pk.a on their loads
+    for (int half = 0; half < 2 && rc == FHE_OK; ++half) {
+        u64 *o = half ? ma.d : mb.d;
+        hipLaunchKernelGGL(fhe::rns_from_i64_kernel, dim3(grid_for(words)), dim3(256), 0, st, (const u64 *)u, o, n, L, (const fhe::Barrett *)r->d_barrett,
+                           (const u64 *)nullptr, batch);
+        if (hipGetLastError() != hipSuccess) { rc = FHE_ERR_HIP; break; }
+        rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, o, log_n, batch * L, st, r->all_pm);
+        if (rc != FHE_OK) break;
+        fhe::NttIo mul;
+        mul.mul = pk_eval + (half ? kw : 0); mul.mul_div = (unsigned)(batch * L); mul.mul_period = (unsigned)L;
+        rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)L, o, log_n, batch * L, st, r->all_pm, mul);
+        if (rc != FHE_OK) break;
+        hipLaunchKernelGGL(fhe::ckks_finish_b_kernel, dim3(grid_for(words)), dim3(256), 0, st, o, (const u64 *)(half ? e0 : e1),
+                           (const u64 *)(half ? nullptr : (pt ? mpt.d : nullptr)), n, L, batch, batch, (const fhe::Barrett *)r->d_barrett, 0);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    return rc;
+}
+
+// scheme/ckks/src/ckks.rs:250-253 `Ckks::mul_constant` after its `encode`: (pt * b, pt * a).rescale().  pt [pt_batch][L][n] encoded
+// plaintexts (pt_batch = 1: one constant for the whole batch, or pt_batch = batch); ct [batch][L][n] -> out [batch][L-1][n]
+int fhe_ckks_mul_plain(const fhe_rns_ctx *r, const uint64_t *pt, size_t pt_batch, const uint64_t *ct_b, const uint64_t *ct_a, uint64_t *out_b, uint64_t *out_a,
+                       size_t n, size_t batch, fhe_mem mem, void *stream) {
+    int rc = ckks_ring_ok(r, n);
+    if (rc != FHE_OK) return rc;
+    if (r->L < 2 || ((!pt || !ct_b || !ct_a || !out_b || !out_a) && batch) || (batch && pt_batch != 1 && pt_batch != batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const int log_n = ilog2(n);
+    const size_t L = r->L, words = batch * L * n, pw = pt_batch * L * n;
+    if (2 * batch * L >= (size_t(1) << 31)) return FHE_ERR_UNSUPPORTED;
+    Mirror mp(pt, pw, mem, true, st), mb(ct_b, words, mem, true, st), ma(ct_a, words, mem, true, st), mob(out_b, batch * (L - 1) * n, mem, false, st),
+        moa(out_a, batch * (L - 1) * n, mem, false, st);
+    if (mp.rc | mb.rc | ma.rc | mob.rc | moa.rc) return FHE_ERR_HIP;
+    StreamWs ws((pw + 2 * words) * sizeof(u64), st);  // the plaintexts' evaluations | pt b | pt a
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *p_eval = ws.as<u64>(), *prod = p_eval + pw;
+    {
+        fhe::NttIo src;
+        src.src = mp.d; src.src_mod = (unsigned)(pt_batch * L);
+        rc = fhe::ntt_fwd_multi(r->d_descs, (unsigned)L, p_eval, log_n, pt_batch * L, st, r->all_pm, src);
+    }
+    if (rc == FHE_OK) rc = fwd_two_sources(r, mb.d, ma.d, prod, log_n, batch * L, st);
+    if (rc == FHE_OK) {
+        fhe::NttIo mul;
+        mul.mul = p_eval; mul.mul_div = (unsigned)(2 * batch * L); mul.mul_period = (unsigned)(pt_batch * L);
+        rc = fhe::ntt_inv_multi(r->d_descs, (unsigned)L, prod, log_n, 2 * batch * L, st, r->all_pm, mul);
+    }
+    if (rc != FHE_OK) return rc;
+    launch_rescale(r, true, rescale_in_block(prod, L * n, r->L - 1, 1, n), mob.d, (L - 1) * n, nullptr, 0, n, batch, st);
+    launch_rescale(r, true, rescale_in_block(prod + words, L * n, r->L - 1, 1, n), moa.d, (L - 1) * n, nullptr, 0, n, batch, st);
+    HIP_TRY(hipGetLastError());
+    rc = mob.sync_out(st);
+    return rc != FHE_OK ? rc : moa.sync_out(st);
 }
 
 }  // extern "C"

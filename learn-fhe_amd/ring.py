@@ -423,6 +423,33 @@ class RnsContext:
         L.check(L.lib().fhe_ckks_ksk_gen(self._h, ps, pp, n, _rng(seed), stream_id, _buf(kb)[0], _buf(ka)[0], mem, st), "fhe_ckks_ksk_gen")
         return kb, ka
 
+    def pk_encrypt(self, pk_b, pk_a, pt, n, batch, seed, stream_id):
+        """scheme/ckks/src/ckks.rs:227-238 -> (b, a) [batch][L][n]; pk [L][n]; pt [batch][L][n] or None."""
+        pb, _, mem, st = _buf(pk_b)
+        pp = _buf(pt)[0] if pt is not None else None
+        b, a = _like(pk_b, (batch, self.L, n)), _like(pk_b, (batch, self.L, n))
+        L.check(L.lib().fhe_ckks_pk_encrypt(self._h, pb, _buf(pk_a)[0], pp, n, batch, _rng(seed), stream_id, _buf(b)[0], _buf(a)[0], mem, st),
+                "fhe_ckks_pk_encrypt")
+        return b, a
+
+    def decrypt(self, sk, ct_b, ct_a, n):
+        """scheme/ckks/src/ckks.rs:240-248: b + a sk -> [batch][L][n]."""
+        pb, cnt, mem, st = _buf(ct_b)
+        batch = cnt // (self.L * n)
+        out = _like(ct_b, (batch, self.L, n))
+        L.check(L.lib().fhe_ckks_decrypt(self._h, _buf(sk)[0], pb, _buf(ct_a)[0], n, batch, _buf(out)[0], mem, st), "fhe_ckks_decrypt")
+        return out
+
+    def mul_plain(self, pt, ct_b, ct_a, n):
+        """scheme/ckks/src/ckks.rs:250-253 after `encode`: (pt b, pt a).rescale() -> (b, a) [batch][L-1][n]; pt [1 or batch][L][n]."""
+        pb, cnt, mem, st = _buf(ct_b)
+        batch = cnt // (self.L * n)
+        pp, pcnt, _, _ = _buf(pt)
+        ob, oa = _like(ct_b, (batch, self.L - 1, n)), _like(ct_b, (batch, self.L - 1, n))
+        L.check(L.lib().fhe_ckks_mul_plain(self._h, pp, pcnt // (self.L * n), pb, _buf(ct_a)[0], _buf(ob)[0], _buf(oa)[0], n, batch, mem, st),
+                "fhe_ckks_mul_plain")
+        return ob, oa
+
     def automorphism(self, limbs, t, n):
         """ckks.rs:127-129 on [batch][L][n]."""
         p, cnt, mem, st = _buf(limbs)

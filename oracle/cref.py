@@ -263,6 +263,22 @@ def ckks_mul(qs, ps, rlk_b, rlk_a, ct0_b, ct0_a, ct1_b, ct1_a):
     return rns_rescale_k(qs, 1, _rns_add(qs, d0, kb)), rns_rescale_k(qs, 1, _rns_add(qs, d1, ka))
 
 
+def rns_from_i64(qs, v):
+    """util/src/ring/rns.rs `RnsRq::from_i64`: a two's-complement i64 vector over every modulus -> [L][n]"""
+    v = np.asarray(v).view(np.int64) if np.asarray(v).dtype == np.uint64 else np.asarray(v, dtype=np.int64)
+    return np.stack([np.mod(v, np.int64(q)).astype(np.uint64) if q < (1 << 63) else None for q in qs])
+
+
+def ckks_decrypt(qs, sk, ct_b, ct_a):
+    """scheme/ckks/src/ckks.rs:240-248: b + a * sk"""
+    return _rns_add(qs, _arr(ct_b), rns_mul(qs, ct_a, rns_from_i64(qs, sk)))
+
+
+def ckks_mul_plain(qs, pt, ct_b, ct_a):
+    """scheme/ckks/src/ckks.rs:250-253 after `encode`: (pt * b, pt * a).rescale()"""
+    return rns_rescale_k(qs, 1, rns_mul(qs, ct_b, pt)), rns_rescale_k(qs, 1, rns_mul(qs, ct_a, pt))
+
+
 def num_threads():
     return lib().ref_num_threads()
 

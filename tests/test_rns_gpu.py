@@ -590,6 +590,57 @@ def test_ckks_device_keys_decrypt_level(fhe, torch_cuda):
         assert max(abs(g - w) for g, w in zip(got, want)) < 2 ** 18, t
 
 
+@pytest.mark.parametrize("log_n,bits,big_l,big_k,batch", [(7, 50, 3, 3, 3), (12, 55, 4, 2, 2), (14, 60, 3, 1, 2), (15, 59, 2, 1, 1)])
+def test_ckks_decrypt_mul_plain_pk_encrypt(fhe, cref, torch_cuda, log_n, bits, big_l, big_k, batch):
+    """`Ckks::decrypt` (scheme/ckks/src/ckks.rs:240-248: b + a sk) and `Ckks::mul_constant` after its `encode` (250-253: (pt b, pt a)
+    .rescale()) bit-equal to the oracle's compositions on random operands, shared and per-ciphertext plaintexts, host and device memory,
+    pt aliasing ct_b; `Ckks::pk_encrypt` (227-238) at decrypt level as the reference's `encrypt_decrypt` test checks it (ckks.rs:316-333):
+    pk = `pk_gen` (143-146) on the device, decrypt(pk_encrypt(pk, pt)) - pt = e u + e1 + e0 sk, small and not zero."""
+    n = 1 << log_n
+    primes = cref.two_adic_primes(bits, log_n + 1, big_l + big_k)
+    qs, ps = [int(x) for x in primes[:big_l]], [int(x) for x in primes[big_l:]]
+    rns = fhe.RnsContext(qs, ps)
+    rng = np.random.Generator(np.random.PCG64(log_n * 10 + big_l))
+    sk = rng.integers(-1, 2, size=n, dtype=np.int64)
+    ct_b, ct_a, pt = rand_limbs(1, qs, n, batch), rand_limbs(2, qs, n, batch), rand_limbs(3, qs, n, batch)
+    sk_d = dev(torch_cuda, sk.view(np.uint64))
+    got = host(rns.decrypt(sk_d, dev(torch_cuda, ct_b), dev(torch_cuda, ct_a), n))
+    for c in range(batch):
+        assert np.array_equal(got[c], cref.ckks_decrypt(qs, sk, ct_b[c], ct_a[c])), c
+    assert np.array_equal(rns.decrypt(sk.view(np.uint64).copy(), ct_b, ct_a, n), got)       # FHE_MEM_HOST
+    import ctypes as C
+    from learn_fhe_amd import _lib as LL
+    db, da = dev(torch_cuda, ct_b), dev(torch_cuda, ct_a)                                   # pt aliasing ct_b
+    st = C.c_void_p(torch_cuda.cuda.current_stream().cuda_stream)
+    LL.check(LL.lib().fhe_ckks_decrypt(rns._h, C.c_void_p(sk_d.data_ptr()), C.c_void_p(db.data_ptr()), C.c_void_p(da.data_ptr()), n, batch,
+                                       C.c_void_p(db.data_ptr()), LL.MEM_DEVICE, st), "fhe_ckks_decrypt")
+    assert np.array_equal(host(db), got)
+    for shared in (True, False):
+        p_in = np.ascontiguousarray(pt[:1]) if shared else pt
+        ob, oa = rns.mul_plain(dev(torch_cuda, p_in), dev(torch_cuda, ct_b), dev(torch_cuda, ct_a), n)
+        for c in range(batch):
+            wb, wa = cref.ckks_mul_plain(qs, p_in[0 if shared else c], ct_b[c], ct_a[c])
+            assert np.array_equal(host(ob)[c], wb) and np.array_equal(host(oa)[c], wa), (shared, c)
+    # pk_gen on the device (an encryption of zero under sk), pk_encrypt, decrypt: noise = e u + e1 + e0 sk
+    like = dev(torch_cuda, np.zeros(1, dtype=np.uint64))
+    sk_z = fhe.sample_zo(0.5, 60, 0, like, n)
+    pkb, pka = rns.sk_encrypt(sk_z, None, n, 1, 61, 0)
+    eb, ea = rns.pk_encrypt(pkb[0].contiguous(), pka[0].contiguous(), dev(torch_cuda, pt), n, batch, 62, 0)
+    eb2, ea2 = rns.pk_encrypt(pkb[0].contiguous(), pka[0].contiguous(), dev(torch_cuda, pt), n, batch, 62, 1)
+    assert not np.array_equal(host(ea), host(ea2)) and not np.array_equal(host(ea)[0], host(ea)[-1] if batch > 1 else host(ea2)[0])
+    dec = host(rns.decrypt(sk_z, eb, ea, n))
+    bound = 19 * n + 19 + 19 * n                                                            # |e| <= 19, |u|, |sk| <= 1
+    for c in range(batch):
+        for l, q in enumerate(qs):
+            diff = (dec[c, l].astype(object) - pt[c, l].astype(object)) % q
+            cen = np.array([int(x) - q if int(x) > q // 2 else int(x) for x in diff], dtype=np.int64)
+            assert np.abs(cen).max() <= bound and np.abs(cen).max() > 0, (c, l)
+            if l:
+                assert np.array_equal(cen, first), (c, l)                                   # the same integer noise on every limb
+            first = cen
+        assert 2.0 * np.sqrt(n) < first.std() < 8.0 * np.sqrt(n), first.std()              # ~ 3.2 sqrt(n/2 + 1 + n/2) in expectation
+
+
 def test_ckks_ops_edge_cases(fhe, cref, torch_cuda):
     """status codes where the reference would panic or has nothing to do: empty batches, a foreign key, a one-limb base, even t"""
     import ctypes as C

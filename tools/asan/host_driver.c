@@ -40,5 +40,14 @@ int main(void) {
     fhe_torus_ctx *t = NULL;
     printf("torus ctx rc=%d\n", fhe_torus_ctx_create(-1, &t));
     if (t) fhe_torus_ctx_destroy(t);
+    {   /* rank-k entries: argument checks that need no device */
+        fhe_tggswk_key *kk = NULL;
+        uint64_t w[8] = {0};
+        printf("tggswk prepare rc=%d\n", fhe_tggswk_prepare(NULL, 2, 8, 8, w, 4, 1, FHE_MEM_HOST, &kk));
+        printf("tggswk ext rc=%d\n", fhe_tggswk_external_product(NULL, NULL, 0, w, 1, FHE_MEM_HOST, NULL));
+        printf("tglwek rotate rc=%d\n", fhe_tglwek_rotate(w, 0, 4, 1, w, 1, FHE_MEM_HOST, NULL));
+        printf("tglwek extract rc=%d\n", fhe_tglwek_sample_extract(w, 1, 4, 9, w, w, 1, FHE_MEM_HOST, NULL));
+        fhe_tggswk_key_destroy(kk);
+    }
     return 0;
 }

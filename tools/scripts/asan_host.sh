@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
 O=${TMPDIR:-/tmp}/fhe_asan
 mkdir -p $O
-for f in ring_api rns_api fhew_api torus_api keygen_api; do
+for f in ring_api rns_api fhew_api torus_api torusk_api keygen_api; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Xarch_host -fsanitize=address,undefined \
       -Xarch_host -fno-omit-frame-pointer -c -o $O/$f.o $R/learn-fhe_amd/csrc/$f.hip
 done
