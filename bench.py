@@ -264,6 +264,28 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=3, verify=True):
     cmux_bytes = (4 * S["d"] + 4) * 8 * S["n"]  # as an RGSW external product: ct in + 2d rows x 2 + ct out
     out["roofline"] = roof(batch / dt, S["n_lwe"] * cmux_bytes, "torus30_blind_rotate_kernel<TorusRing30<10>> (630 CMUXes in one launch)",
                            "%d CMUXes x %d B per gate (TLWE key switch not counted); TGGSW rows are cache hits: bound by VALU issue" % (S["n_lwe"], cmux_bytes))
+    # the same gate through the f64 FFT product the reference itself computes with (util/src/ring/fft/c64.rs; fhe_tggsw_prepare_fft64):
+    # floating point, so NOT bit-exact -- checked against the exact mode's accumulators within the reference's own error bound
+    fkey = F.TggswKey(S["t"], S["log_b"], S["d"], S["raw"][0], S["raw"][1], S["n"], fft64=True)
+    fdt = _timeit(torch, lambda: fkey.bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"]), reps)
+    f = {"mode": "fft64: one pass of N/2-point complex f64 transforms per CMUX (the reference's algorithm) instead of three passes of 30-bit NTTs",
+         "gate_bootstraps_per_sec": batch / fdt, "vs_exact_mode": dt / fdt}
+    if verify:
+        # ONE CMUX over the whole batch in both modes (the exact mode's gate is checked against the oracle above): every coefficient within
+        # the reference's bound.  (Whole accumulators are not comparable: the first digit that rounds the other way re-randomises the masks
+        # of everything after it -- decode-level equality of whole gates is what tests/test_torus_fft64_gpu.py checks, on valid keys.)
+        c0a, c0b, c1a, c1b = (torch.randint(-(1 << 63), (1 << 63) - 1, (batch, S["n"]), dtype=torch.int64, device=dev) for _ in range(4))
+        xa, xb = S["key"].cmux(7, c0a, c0b, c1a, c1b)
+        ya, yb = fkey.cmux(7, c0a, c0b, c1a, c1b)
+        err = max(int((xa - ya).abs().max().item()), int((xb - yb).abs().max().item()))  # wrapping int64 differences = signed torus distance
+        bound = 2 * S["d"] * (1 << (64 + S["log_b"] + 10 - 53))
+        f["max_abs_error_of_one_cmux_vs_exact_mode"] = err
+        f["error_bound"] = bound
+        f["verified"] = bool(0 < err <= bound)
+        f["verification"] = ("one CMUX of all %d ciphertexts (2 x %d coefficients each) against the exact mode: max |difference| %d = 2^%.1f of the 2^64 torus, "
+                             "bound 2d x 2^(64 + log_b + log_n - 53) (util/src/ring/fft/c64.rs:186-208 per product)" % (batch, S["n"], err, __import__("math").log2(max(err, 1))))
+    f["roofline"] = roof(batch / fdt, S["n_lwe"] * cmux_bytes, "torusf_blind_rotate_kernel<WaveRing<9,2>> (630 CMUXes in one launch)", "as above")
+    out["fft64"] = f
     return out
 
 

@@ -287,6 +287,14 @@ int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int lo
 int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
                       fhe_mem mem, fhe_tggsw_key **out);
 void fhe_tggsw_key_destroy(fhe_tggsw_key *key);
+/* The same key prepared for the f64 FFT product the reference itself computes with (util/src/ring/fft/c64.rs:11-56: fold N reals into
+ * N/2 complex values, transform, multiply, transform back, `f64_mod_u64`).  Every entry point below that takes the key (external
+ * product, cmux, blind rotation, bootstrap) then runs that mode: one pass of half-size complex transforms where the exact path runs
+ * three passes of 30-bit ones.  NOT exact and not bit-reproducible against anything (the reference's own low bits depend on its
+ * libm): per product |result - exact| <= 2^(64 + log_b + log2 n - 53), the reference's own bound (c64.rs:186-208); decode-level
+ * results agree.  The exact mode (fhe_tggsw_prepare) stays the default and the parity checker. */
+int fhe_tggsw_prepare_fft64(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
+                            fhe_mem mem, fhe_tggsw_key **out);
 /* scheme/tfhe/src/tggsw.rs:100-112 `Tggsw::external_product(param, key[index], ct)`, in place on [batch][n] a / b. */
 int fhe_tggsw_external_product(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, uint64_t *ct_a, uint64_t *ct_b,
                                size_t batch, fhe_mem mem, void *stream);

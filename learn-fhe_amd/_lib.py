@@ -120,6 +120,7 @@ def lib():
         L.fhe_torus_decompose.argtypes = [ci, ci, vp, sz, sz, vp, ci, vp]
         L.fhe_torus_mul.argtypes = [vp, vp, vp, ci, sz, sz, ci, vp]
         L.fhe_tggsw_prepare.argtypes = [vp, ci, ci, vp, vp, sz, sz, ci, C.POINTER(vp)]
+        L.fhe_tggsw_prepare_fft64.argtypes = [vp, ci, ci, vp, vp, sz, sz, ci, C.POINTER(vp)]
         L.fhe_tggsw_key_destroy.argtypes = [vp]
         L.fhe_tggsw_key_destroy.restype = None
         L.fhe_tggsw_external_product.argtypes = [vp, vp, sz, vp, vp, sz, ci, vp]

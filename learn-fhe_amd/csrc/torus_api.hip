@@ -1,6 +1,7 @@
 // extern "C" entry points for SURVEY.md section 8(a) row T: the TFHE torus path, k = 1.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -73,10 +74,35 @@ using TorusRing30 = fhe::WaveRing<LN, (LN <= 9 ? LN - 6 : 3)>;
         default: return FHE_ERR_UNSUPPORTED;                               \
     }
 
+// fft64 mode: a team over the N / 2 complex slots of a polynomial, 4 slots per lane from N = 1024 up (two waves per SIMD)
+constexpr int TF_LOG_CAP = 11;
+template <int LN>
+using TorusRingF = fhe::WaveRing<LN - 1, (LN - 1 <= 8 ? LN - 1 - 6 : 2)>;
+#ifndef FHE_TF_MIN_WAVES
+#define FHE_TF_MIN_WAVES 2
+#endif
+constexpr int TF_MIN_WAVES = FHE_TF_MIN_WAVES;
+
+template <class K>
+int set_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return FHE_OK;
+}
+
 int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, u64 *a, u64 *b, size_t batch, const u64 *rot,
                 size_t rot_stride, hipStream_t st) {
     const size_t n = size_t(1) << key->log_n;
     const size_t per = size_t(2 * key->d) * 2 * n;
+    if (key->d_rowsf) {  // fft64 mode
+        const double2 *frows = key->d_rowsf + index * (per / 2);
+        TORUS_DISPATCH(key->log_n, {
+            typedef TorusRingF<LN> WR;
+            hipLaunchKernelGGL((fhe::torusf_cmux_kernel<WR, TF_MIN_WAVES>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
+                               fhe::TorusF<WR>::LDS_BYTES, st, a, b, (unsigned)batch, frows, key->P, rot, rot_stride, (const double2 *)t->d_twf);
+        });
+        HIP_TRY(hipGetLastError());
+        return FHE_OK;
+    }
     if (key->d_rows30) {  // three 30-bit primes
         const size_t plane = key->count * per;
         TORUS_DISPATCH(key->log_n, {
@@ -112,6 +138,7 @@ void fhe_torus_ctx_destroy(fhe_torus_ctx *t) {
         DeviceGuard guard(t->device);
         if (t->d_descs) (void)hipFree(t->d_descs);
         if (t->d_blob30) (void)hipFree(t->d_blob30);
+        if (t->d_twf) (void)hipFree(t->d_twf);
     }
     fhe_ctx_destroy(t->mods[0]);
     fhe_ctx_destroy(t->mods[1]);
@@ -171,6 +198,18 @@ int fhe_torus_ctx_create(int device, fhe_torus_ctx **out) {
         C.h0 = (uint32_t)(half % p0);
         C.h1 = (uint32_t)((half / p0) % p1);
         C.h2 = (uint32_t)(half / p0 / p1);
+    }
+    {   // fft64 mode: the twiddle tree of torusf_kernels.hpp, node 2^l + i -> cis(pi (2 bitrev_l(i) + 1) / 2^(l+1))
+        std::vector<double2> tw(size_t(1) << TF_LOG_CAP);
+        tw[0] = double2{1.0, 0.0};
+        for (int l = 0; l < TF_LOG_CAP; ++l)
+            for (unsigned i = 0; i < (1u << l); ++i) {
+                const double ang = M_PI * double(2 * (l ? fhe::bitrev(i, l) : 0u) + 1) / double(2u << l);
+                tw[(size_t(1) << l) + i] = double2{cos(ang), sin(ang)};
+            }
+        e = hipMalloc((void **)&t->d_twf, tw.size() * sizeof(double2));
+        if (e == hipSuccess) e = hipMemcpy(t->d_twf, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { g_last_hip = (int)e; fhe_torus_ctx_destroy(t); return FHE_ERR_HIP; }
     }
     *out = t;
     return FHE_OK;
@@ -244,6 +283,7 @@ void fhe_tggsw_key_destroy(fhe_tggsw_key *k) {
         DeviceGuard guard(k->t->device);
         if (k->d_rows[0]) (void)hipFree(k->d_rows[0]);
         if (k->d_rows30) (void)hipFree(k->d_rows30);
+        if (k->d_rowsf) (void)hipFree(k->d_rowsf);
     }
     delete k;
 }
@@ -312,6 +352,39 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     if (!k) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); return FHE_ERR_INVALID; }
     k->t = t; k->log_n = log_n; k->log_b = log_b; k->d = d; k->count = count; k->P = P;
     k->d_rows[0] = dst; k->d_rows[1] = dst ? dst + 2 * words : nullptr; k->d_rows30 = dst30;
+    *out = k;
+    return FHE_OK;
+}
+
+// The same key prepared for the f64 FFT product the reference itself uses (util/src/ring/fft/c64.rs:11-56): every entry point that
+// takes the key then runs torusf_kernels.hpp.  NOT exact: per product |result - exact| <= 2^(64 + log_b + log2 n - 53) (c64.rs:186-208).
+int fhe_tggsw_prepare_fft64(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count, fhe_mem mem,
+                            fhe_tggsw_key **out) {
+    if (!out) return FHE_ERR_INVALID;
+    *out = nullptr;
+    if (!t || !rows_a || !rows_b || !is_pow2(n) || count == 0) return FHE_ERR_INVALID;
+    const int log_n = ilog2(n);
+    if (log_n < 8 || log_n > 11) return FHE_ERR_UNSUPPORTED;
+    fhe::TDecomp P;
+    int rc = make_tdecomp(log_b, d, &P);
+    if (rc != FHE_OK) return rc;
+    DeviceGuard guard(t->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * 2 * d, words = rows * n;
+    hipStream_t st = nullptr;
+    Mirror ma(rows_a, words, mem, true, st), mb(rows_b, words, mem, true, st);
+    if (ma.rc | mb.rc) return FHE_ERR_HIP;
+    double2 *dst = nullptr;
+    HIP_TRY(hipMalloc((void **)&dst, 2 * rows * (n / 2) * sizeof(double2)));
+    TORUS_DISPATCH(log_n, {
+        typedef TorusRingF<LN> WR;
+        hipLaunchKernelGGL(fhe::torusf_key_prepare_kernel<WR>, dim3((unsigned)((2 * rows + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), fhe::TorusF<WR>::LDS_BYTES, st,
+                           (const u64 *)ma.d, (const u64 *)mb.d, rows, (const double2 *)t->d_twf, dst);
+    });
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(dst); return FHE_ERR_HIP; }
+    fhe_tggsw_key *k = new (std::nothrow) fhe_tggsw_key();
+    if (!k) { (void)hipFree(dst); return FHE_ERR_INVALID; }
+    k->t = t; k->log_n = log_n; k->log_b = log_b; k->d = d; k->count = count; k->P = P; k->d_rowsf = dst;
     *out = k;
     return FHE_OK;
 }
@@ -415,7 +488,14 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
     // acc = (0, v).rotate(-b), then fold cmux(brk_i, acc, acc.rotate(a_i)) (bootstrapping.rs:91-95): one launch, the
     // accumulator never leaves the registers of the team that owns the ciphertext
     int rc = FHE_OK;
-    if (brk->d_rows30) {  // three 30-bit primes
+    if (brk->d_rowsf) {  // fft64 mode
+        TORUS_DISPATCH(brk->log_n, {
+            typedef TorusRingF<LN> WR;
+            hipLaunchKernelGGL((fhe::torusf_blind_rotate_kernel<WR, TF_MIN_WAVES>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
+                               fhe::TorusF<WR>::LDS_BYTES, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe, (unsigned)batch,
+                               (const double2 *)brk->d_rowsf, brk->P, (const double2 *)t->d_twf, moa.d, mob.d);
+        });
+    } else if (brk->d_rows30) {  // three 30-bit primes
         const size_t plane = brk->count * size_t(2 * brk->d) * 2 * n;
         // base <= 2^8 and at most 8 limbs (cfg5: base 2^7, d = 3): the CMUX digits are computed once and parked as bytes, the
         // multiply-accumulate runs unreduced (torus30_kernels.hpp); lab switch NO_PACKED_DIGITS keeps the older kernel (bit-identical)

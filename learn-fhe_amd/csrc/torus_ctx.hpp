@@ -7,6 +7,7 @@
 #include "ctx.hpp"
 #include "torus_kernels.hpp"
 #include "torus30_kernels.hpp"
+#include "torusf_kernels.hpp"
 
 struct fhe_torus_ctx {
     int device = -1;
@@ -16,6 +17,8 @@ struct fhe_torus_ctx {
     // the three-prime 30-bit path (torus30_kernels.hpp)
     void *d_blob30 = nullptr;         // twiddle tables + descriptors
     fhe::Torus30Consts T30{};
+    // the f64 FFT mode (torusf_kernels.hpp): T[2^l + i] = cis(pi (2 bitrev_l(i) + 1) / 2^(l+1)), 2^11 entries
+    double2 *d_twf = nullptr;
 };
 
 struct fhe_tggsw_key {
@@ -24,6 +27,7 @@ struct fhe_tggsw_key {
     size_t count = 0;
     u64 *d_rows[2] = {nullptr, nullptr};  // per prime: [count][2d][2][N] evaluation domain, key_perm layout
     unsigned *d_rows30 = nullptr;         // 30-bit path: [3 primes][count][2d][2][N] Montgomery residues, key_perm30 layout
+    double2 *d_rowsf = nullptr;           // fft64 mode: [count][2d][2][N / 2] complex evaluations (torusf_kernels.hpp)
     fhe::TDecomp P{};
 };
 

@@ -1,0 +1,286 @@
+// Row T the way the reference computes it: the torus products of a CMUX through an f64 complex FFT (util/src/ring/fft/c64.rs:11-108:
+// fold N reals into N/2 complex values, transform, multiply pointwise, transform back, round each f64 to u64 mod 2^64).  The default
+// path of this backend is EXACT (torus_kernels.hpp, torus30_kernels.hpp); this one is the opt-in `fft64` mode of a prepared key
+// (fhe_tggsw_prepare_fft64): the same team-per-ciphertext kernels with ONE pass of half-size complex transforms where the exact path
+// runs three passes of full-size 30-bit ones.  Its results are NOT bit-identical to anything -- neither to the exact product nor to
+// the reference, whose own low bits depend on libm's `cis` -- and are accepted the way the reference accepts its own product:
+// |result - exact| <= 2^(64 + log_b + log_n - 53) per product (c64.rs:186-208), decode-level equality of everything built on it.
+//
+// The transform.  For a real polynomial a of degree < N and zeta = exp(i pi / N), b_k = a_k + i a_{k+N/2} is the left output of layer
+// 0 of the size-N negacyclic transform (twiddle zeta^(N/2) = i), and the rest of that transform restricted to the left half is a
+// size-N/2 Cooley-Tukey network over C with the twiddles T[2^l + i] = cis(pi (2 bitrev_l(i) + 1) / 2^(l+1)) of the left sub-tree:
+// exactly what the integer kernels call a sub-transform with pb = 1, prefix = 0 (arith.hpp tw_load).  So the generic pass machinery
+// (ntt_kernels.hpp fwd_run / inv_run) runs unchanged on the policy below, no separate twist (c64.rs:19-29 `to_c64_twisted` multiplies
+// by zeta^k first and then runs a cyclic transform: the same evaluations, one complex product per coefficient more).  The left half
+// holds the evaluations at zeta^(4j+1); the other half would hold their conjugates.
+#pragma once
+#include "torus_kernels.hpp"
+
+namespace fhe {
+
+struct ArithC64 {
+    typedef double2 Elem;   // re, im
+    typedef double2 TwRaw;
+    typedef double2 TwReg;
+    static constexpr int PREFETCH = 0;
+    static constexpr bool GS_FOLDS = false;
+    static constexpr int CT_LAYERS = 64;
+    static constexpr bool PASS_FOLD = false;
+    static constexpr int GS_SPAN = 0;
+    static __device__ constexpr bool ct_fold_at(int) { return false; }
+    struct K {
+        const FHE_CONST double2 *tw;  // T[j], j < 2^log_cap: the size-independent table above (constant address space: scalar loads)
+        double scale;                 // 1 / (N / 2)
+        int pb, prefix;               // 1, 0: the left sub-tree
+    };
+    static __device__ __forceinline__ K make(const double2 *tw, int log_m) { return K{(const FHE_CONST double2 *)tw, 1.0 / double(1 << log_m), 1, 0}; }
+    template <bool INV>
+    static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
+        const FHE_CONST double2 *p = k.tw + idx;
+        TwRaw r;
+        r.x = p->x; r.y = p->y;
+        return r;
+    }
+    static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return r; }
+    // (X, Y) <- (X + w Y, X - w Y)
+    static __device__ __forceinline__ void ct(Elem &X, Elem &Y, const TwReg &w, const K &) {
+        const double tr = fma(-w.y, Y.y, w.x * Y.x), ti = fma(w.y, Y.x, w.x * Y.y);
+        const Elem x = X;
+        X.x = x.x + tr; X.y = x.y + ti;
+        Y.x = x.x - tr; Y.y = x.y - ti;
+    }
+    // (X, Y) <- (X + Y, (X - Y) conj(w)): |w| = 1, the inverse twiddle is the conjugate (c64.rs:117)
+    template <int PH>
+    static __device__ __forceinline__ void gs(Elem &X, Elem &Y, const TwReg &w, const K &) {
+        const double dr = X.x - Y.x, di = X.y - Y.y;
+        X.x += Y.x; X.y += Y.y;
+        Y.x = fma(di, w.y, dr * w.x);
+        Y.y = fma(-dr, w.y, di * w.x);
+    }
+    static __device__ __forceinline__ Elem gs_fold(Elem x, const K &) { return x; }
+    static __device__ __forceinline__ Elem fold(Elem x, const K &) { return x; }
+    static __device__ __forceinline__ Elem canon_fwd(Elem x, const K &) { return x; }
+    static __device__ __forceinline__ Elem finish_inv(Elem x, const K &k) { return Elem{x.x * k.scale, x.y * k.scale}; }
+};
+
+// util/src/ring/fft/c64.rs:69-85 `f64_mod_u64`: the integer nearest to v (ties away from zero), mod 2^64
+__device__ __forceinline__ u64 f64_mod_u64(double v) {
+    const u64 bits = (u64)__double_as_longlong(v);
+    const int exponent = int((bits >> 52) & 0x7ff);
+    const u64 mantissa = (bits << 11) | 0x8000000000000000ull;
+    const int shift = 1086 - exponent;
+    u64 value = 0;
+    if (shift >= -63 && shift <= 0) value = mantissa << (-shift);
+    else if (shift >= 1 && shift <= 64) value = ((mantissa >> (shift - 1)) + 1) >> 1;
+    return (bits >> 63) ? 0 - value : value;
+}
+
+// W = WaveRing over the M = N / 2 complex elements of a polynomial.  A lane holds the torus coefficients of its complex slots as
+// c[e] = coefficient k_e, c[E + e] = coefficient k_e + M (k_e = coef_index<W>(lane, e)): the fold needs no exchange.
+template <class W>
+struct TorusF {
+    static constexpr int M = W::N, N = 2 * W::N, E = W::E;
+    static constexpr int LDS_WORDS = 2 * W::PN;  // 8-byte words per team: the exchange image (PN complex slots) = the rotation image (N u64 + padding)
+    static constexpr size_t LDS_BYTES = size_t(LDS_WORDS) * 8 * W::TEAMS;
+};
+
+template <class W>
+__device__ __forceinline__ void pairs_load(u64 (&c)[2 * W::E], const u64 *__restrict__ g, int lane) {
+#pragma unroll
+    for (int e = 0; e < W::E; ++e) {
+        const int k = coef_index<W>(lane, e);
+        c[e] = g[k]; c[W::E + e] = g[k + W::N];
+    }
+}
+template <class W>
+__device__ __forceinline__ void pairs_store(const u64 (&c)[2 * W::E], u64 *__restrict__ g, int lane) {
+#pragma unroll
+    for (int e = 0; e < W::E; ++e) {
+        const int k = coef_index<W>(lane, e);
+        g[k] = c[e]; g[k + W::N] = c[W::E + e];
+    }
+}
+
+// c <- c * X^r (ring.rs:299-313 on T64), r in [0, 2N), through the team's image
+template <class W>
+__device__ __forceinline__ void pairs_rotate(u64 (&c)[2 * W::E], unsigned r, int lane, u64 *img) {
+    constexpr int E = W::E, M = W::N, N = 2 * M;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned pos = (unsigned(coef_index<W>(lane, e) + h * M) + r) & (2 * N - 1);
+            img[lds_phys(pos & (N - 1))] = pos < N ? c[h * E + e] : 0 - c[h * E + e];
+        }
+    exchange_sync<W::WAVE>();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < E; ++e) c[h * E + e] = img[lds_phys(coef_index<W>(lane, e) + h * M)];
+    exchange_sync<W::WAVE>();
+}
+
+// key rows: [row][a | b][M] complex evaluations; evaluation lane * E + r of a row sits at slot r * TEAM + lane: a team's registers
+// load as coalesced 16-byte accesses
+template <class W>
+struct KeyRowF {
+    double2 a[W::E], b[W::E];
+};
+template <class W>
+__device__ __forceinline__ void load_rowf(KeyRowF<W> &kr, const double2 *__restrict__ row, int lane) {
+#pragma unroll
+    for (int r = 0; r < W::E; ++r) { kr.a[r] = row[r * W::TEAM + lane]; kr.b[r] = row[W::N + r * W::TEAM + lane]; }
+}
+__device__ __forceinline__ void cmac(double2 &s, const double2 &x, const double2 &k) {
+    s.x = fma(x.x, k.x, fma(-x.y, k.y, s.x));
+    s.y = fma(x.x, k.y, fma(x.y, k.x, s.y));
+}
+
+// (sa, sb) <- sum over the 2d limbs of (da, db) of FFT(limb) (.) (row.a, row.b), transformed back: the two halves of the external
+// product (tggsw.rs:100-112, k = 1) as complex slot values, coefficient layout, before rounding
+template <class W>
+__device__ __forceinline__ void teamf_gadget(const u64 (&da)[2 * W::E], const u64 (&db)[2 * W::E], const double2 *__restrict__ rows, const TDecomp &P,
+                                             int lane, double2 *lds, const ArithC64::K &k, double2 (&sa)[W::E], double2 (&sb)[W::E]) {
+    using A = ArithC64;
+    constexpr int E = W::E;
+    u64 st[2 * E];
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) st[e] = tdecomp_init(da[e], P);
+#pragma unroll
+    for (int e = 0; e < E; ++e) sa[e] = sb[e] = double2{0.0, 0.0};
+    KeyRowF<W> kr;
+    load_rowf<W>(kr, rows, lane);
+#pragma unroll 1
+    for (int j = 0; j < 2 * P.d; ++j) {
+        if (j == P.d) {
+#pragma unroll
+            for (int e = 0; e < 2 * E; ++e) st[e] = tdecomp_init(db[e], P);
+        }
+        double2 x[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {  // signed digits as reals: exact (c64.rs:25 `to_i64() as f64`)
+            x[e].x = (double)(long long)tdecomp_next(st[e], P);
+            x[e].y = (double)(long long)tdecomp_next(st[E + e], P);
+        }
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { cmac(sa[e], x[e], kr.a[e]); cmac(sb[e], x[e], kr.b[e]); }
+        if (j + 1 < 2 * P.d) load_rowf<W>(kr, rows + size_t(j + 1) * 2 * W::N, lane);
+    }
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(sa, lane, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const double2 t = sa[e]; sa[e] = sb[e]; sb[e] = t; }
+    }
+}
+
+// r = 0xffffffff: plain external product, (ca, cb) <- key (.) (ca, cb); else one CMUX step of the blind rotation (bootstrapping.rs:91-95)
+template <class W>
+__device__ __forceinline__ void teamf_cmux(u64 (&ca)[2 * W::E], u64 (&cb)[2 * W::E], unsigned r, const double2 *__restrict__ rows, const TDecomp &P,
+                                           const ArithC64::K &k, int lane, u64 *lds64) {
+    constexpr int E = W::E;
+    const bool plain = r == 0xffffffffu;
+    if (r == 0) return;  // team-uniform
+    u64 da[2 * E], db[2 * E];
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) { da[e] = ca[e]; db[e] = cb[e]; }
+    if (!plain) {
+        pairs_rotate<W>(da, r, lane, lds64);
+        pairs_rotate<W>(db, r, lane, lds64);
+#pragma unroll
+        for (int e = 0; e < 2 * E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
+    }
+    double2 sa[E], sb[E];
+    teamf_gadget<W>(da, db, rows, P, lane, reinterpret_cast<double2 *>(lds64), k, sa, sb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u64 a0 = f64_mod_u64(sa[e].x), a1 = f64_mod_u64(sa[e].y), b0 = f64_mod_u64(sb[e].x), b1 = f64_mod_u64(sb[e].y);
+        if (plain) { ca[e] = a0; ca[E + e] = a1; cb[e] = b0; cb[E + e] = b1; }
+        else { ca[e] += a0; ca[E + e] += a1; cb[e] += b0; cb[E + e] += b1; }
+    }
+}
+
+template <class W, int MIN_WAVES>
+__global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_cmux_kernel(u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch,
+                                                                            const double2 *__restrict__ rows, TDecomp P, const u64 *__restrict__ rot,
+                                                                            size_t rot_stride, const double2 *__restrict__ tw) {
+    constexpr int E = W::E, N = 2 * W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS;
+    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
+    u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
+    u64 ca[2 * E], cb[2 * E];
+    pairs_load<W>(ca, ga, lane);
+    pairs_load<W>(cb, gb, lane);
+    teamf_cmux<W>(ca, cb, rot ? unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1) : 0xffffffffu, rows, P, k, lane, lds);
+    pairs_store<W>(ca, ga, lane);
+    pairs_store<W>(cb, gb, lane);
+}
+
+// bootstrapping.rs:84-96 in one launch, as torus30_blind_rotate_kernel; rows: [n_lwe][2d][2][M] complex
+template <class W, int MIN_WAVES>
+__global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_kernel(const u64 *__restrict__ v, const u64 *__restrict__ a_tilde,
+                                                                                    const u64 *__restrict__ b_tilde, unsigned n_lwe, unsigned batch,
+                                                                                    const double2 *__restrict__ rows, TDecomp P,
+                                                                                    const double2 *__restrict__ tw, u64 *__restrict__ out_a,
+                                                                                    u64 *__restrict__ out_b) {
+    constexpr int E = W::E, N = 2 * W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS;
+    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
+    u64 ca[2 * E], cb[2 * E];
+    pairs_load<W>(cb, v, lane);
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) ca[e] = 0;
+    pairs_rotate<W>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);
+    const size_t per = size_t(2 * P.d) * 2 * W::N;
+    const u64 *a = a_tilde + size_t(ct) * n_lwe;
+#pragma unroll 1
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const unsigned r = __builtin_amdgcn_readfirstlane(unsigned(a[i]) & (2 * N - 1));
+        teamf_cmux<W>(ca, cb, r, rows + i * per, P, k, lane, lds);
+    }
+    pairs_store<W>(ca, out_a + size_t(ct) * N, lane);
+    pairs_store<W>(cb, out_b + size_t(ct) * N, lane);
+}
+
+// Measured and dropped (round 3): one wave per POLYNOMIAL for N <= 1024 -- wave 0 owns the a half of the ciphertext, wave 1 the b half, each
+// runs its d forward transforms alone (eight slots per lane, three passes, wave-private exchanges, no barrier), one hand-over of partial
+// sums per CMUX, accumulator half parked in LDS (246 registers, no spill): 68.9 k gates/s at cfg5 against 74.2 k for the team form above
+// (17.3 k against 26.5 k at batch 256: one ciphertext per block leaves a CU two waves) -- half the LDS traffic and two barriers per CMUX
+// instead of fifty, but eight-slot transforms with two waves per SIMD have nothing to hide their dependency chains behind.
+
+// key preparation: signed torus rows [rows][N] (a | b) -> complex evaluations [row][a | b][M] in the KeyRowF layout
+// (c64.rs:19-29: key words converted with `to_i64() as f64`, round to nearest)
+template <class W>
+__global__ __launch_bounds__(W::THREADS) void torusf_key_prepare_kernel(const u64 *__restrict__ rows_a, const u64 *__restrict__ rows_b, size_t n_rows,
+                                                                        const double2 *__restrict__ tw, double2 *__restrict__ out) {
+    constexpr int E = W::E, M = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const size_t job = size_t(blockIdx.x) * W::TEAMS + team;  // (row, a|b)
+    if (job >= 2 * n_rows) return;
+    double2 *lds = reinterpret_cast<double2 *>(reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS);
+    const u64 *src = ((job & 1) ? rows_b : rows_a) + (job >> 1) * (2 * M);
+    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
+    double2 x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = coef_index<W>(lane, e);
+        x[e].x = (double)(long long)src[c];
+        x[e].y = (double)(long long)src[c + M];
+    }
+    fwd_run<ArithC64, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+    double2 *dst = out + job * M;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[e * W::TEAM + lane] = x[e];
+}
+
+}  // namespace fhe

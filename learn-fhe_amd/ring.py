@@ -578,13 +578,16 @@ class TorusContext:
 class TggswKey:
     """Prepared TGGSW ciphertexts, k = 1 (scheme/tfhe/src/tggsw.rs:44-88)."""
 
-    def __init__(self, t: TorusContext, log_b, d, rows_a, rows_b, n):
-        self.t, self.log_b, self.d, self.n = t, log_b, d, n
+    def __init__(self, t: TorusContext, log_b, d, rows_a, rows_b, n, fft64=False):
+        """fft64: the f64 FFT product of the reference (util/src/ring/fft/c64.rs) instead of the exact one -- within the reference's
+        error bound of the exact results, not bit-identical to anything."""
+        self.t, self.log_b, self.d, self.n, self.fft64 = t, log_b, d, n, fft64
         pa, cnt, mem, _ = _buf(rows_a)
         pb, _, _, _ = _buf(rows_b)
         self.count = cnt // (2 * d * n)
         self._h = C.c_void_p()
-        L.check(L.lib().fhe_tggsw_prepare(t.handle, log_b, d, pa, pb, n, self.count, mem, C.byref(self._h)), "fhe_tggsw_prepare")
+        fn = L.lib().fhe_tggsw_prepare_fft64 if fft64 else L.lib().fhe_tggsw_prepare
+        L.check(fn(t.handle, log_b, d, pa, pb, n, self.count, mem, C.byref(self._h)), "fhe_tggsw_prepare")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
