@@ -78,10 +78,7 @@ using TorusRing30 = fhe::WaveRing<LN, (LN <= 9 ? LN - 6 : 3)>;
 constexpr int TF_LOG_CAP = 11;
 template <int LN>
 using TorusRingF = fhe::WaveRing<LN - 1, (LN - 1 <= 8 ? LN - 1 - 6 : 2)>;
-#ifndef FHE_TF_MIN_WAVES
-#define FHE_TF_MIN_WAVES 2
-#endif
-constexpr int TF_MIN_WAVES = FHE_TF_MIN_WAVES;
+constexpr int TF_MIN_WAVES = 2;
 
 template <class K>
 int set_lds(K kernel, size_t lds) {

@@ -251,6 +251,11 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
     pairs_store<W>(cb, out_b + size_t(ct) * N, lane);
 }
 
+// Measured and dropped (round 3): PAIRED transforms -- an element type of two complex values (limb p of the a half with limb p of the b half,
+// the two outputs on the way back) shares every twiddle fetch, exchange and barrier between two transforms: four trips through the network
+// per CMUX instead of eight, 228 registers -- 72.8 k gates/s at cfg5 against 74.2-75.0 k unpaired: barriers are not what the kernel waits for.
+// Measured and dropped: THREE waves per SIMD (accumulator parked in LDS during the gadget, 168 registers with 20 spilled, six ciphertexts
+// per CU): 76.6 k at batch 1536, 70.7 k at 4096 (77.8 k with two waves), 58.1 k at 1024 (two thirds of a generation).
 // Measured and dropped (round 3): one wave per POLYNOMIAL for N <= 1024 -- wave 0 owns the a half of the ciphertext, wave 1 the b half, each
 // runs its d forward transforms alone (eight slots per lane, three passes, wave-private exchanges, no barrier), one hand-over of partial
 // sums per CMUX, accumulator half parked in LDS (246 registers, no spill): 68.9 k gates/s at cfg5 against 74.2 k for the team form above
