@@ -217,18 +217,28 @@ __global__ __launch_bounds__(W::THREADS, W::MIN_WAVES) void torus30_blind_rotate
 template <class W>
 __device__ __forceinline__ void park_digits30(const u64 (&da)[W::E], const u64 (&db)[W::E], const TDecomp &P, int lane, unsigned *dig) {
     constexpr int E = W::E;
+    // the gadgets this path serves have log_b d <= 28 bits: after the rounding shift the decomposition state fits one dword, and the
+    // recurrence of decompose.rs:124-134 runs on 32-bit words (half the instructions of the u64 form; same digits)
+    const unsigned mask = (unsigned)P.mask;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        u64 st[E];
+        unsigned st[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) st[e] = tdecomp_init(half ? db[e] : da[e], P);
+        for (int e = 0; e < E; ++e) st[e] = (unsigned)(((half ? db[e] : da[e]) + P.rnd) >> P.rb);
 #pragma unroll 1
         for (int j = 0; j < P.d; ++j) {
 #pragma unroll
             for (int r4 = 0; r4 < E / 4; ++r4) {
                 unsigned w = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) w |= ((unsigned)tdecomp_next(st[4 * r4 + b], P) & 0xffu) << (8 * b);  // |digit| <= 2^(log_b-1) <= 128... the byte
+                for (int b = 0; b < 4; ++b) {
+                    unsigned &c = st[4 * r4 + b];
+                    const unsigned limb = c & mask;
+                    c >>= P.log_b;
+                    const unsigned carry = (((limb - 1) | c) & limb) >> (P.log_b - 1);
+                    c += carry;
+                    w |= ((limb - (carry << P.log_b)) & 0xffu) << (8 * b);  // |digit| <= 2^(log_b-1) <= 64: a signed byte
+                }
                 dig[((half * P.d + j) * (E / 4) + r4) * W::TEAM + lane] = w;
             }
         }

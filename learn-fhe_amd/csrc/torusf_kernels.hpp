@@ -28,15 +28,19 @@ struct ArithC64 {
     static constexpr bool PASS_FOLD = false;
     static constexpr int GS_SPAN = 0;
     static __device__ constexpr bool ct_fold_at(int) { return false; }
+    // T[j], j < 2 M, staged in LDS by the kernel (stage_twiddles): from the third pass on every lane needs its own entries -- nine 16-byte
+    // fetches per transform that were vector loads from the table in HBM/L2 (a third of the wave cycles parked); an LDS read has a
+    // quarter of their latency and the wave-uniform entries of the first passes come as broadcasts
+    typedef const __attribute__((address_space(3))) double2 *LdsTw;
     struct K {
-        const FHE_CONST double2 *tw;  // T[j], j < 2^log_cap: the size-independent table above (constant address space: scalar loads)
+        LdsTw tw;
         double scale;                 // 1 / (N / 2)
         int pb, prefix;               // 1, 0: the left sub-tree
     };
-    static __device__ __forceinline__ K make(const double2 *tw, int log_m) { return K{(const FHE_CONST double2 *)tw, 1.0 / double(1 << log_m), 1, 0}; }
+    static __device__ __forceinline__ K make(const double2 *tw_lds, int log_m) { return K{(LdsTw)tw_lds, 1.0 / double(1 << log_m), 1, 0}; }
     template <bool INV>
     static __device__ __forceinline__ TwRaw fetch(const K &k, int idx) {
-        const FHE_CONST double2 *p = k.tw + idx;
+        const LdsTw p = k.tw + idx;
         TwRaw r;
         r.x = p->x; r.y = p->y;
         return r;
@@ -81,8 +85,18 @@ template <class W>
 struct TorusF {
     static constexpr int M = W::N, N = 2 * W::N, E = W::E;
     static constexpr int LDS_WORDS = 2 * W::PN;  // 8-byte words per team: the exchange image (PN complex slots) = the rotation image (N u64 + padding)
-    static constexpr size_t LDS_BYTES = size_t(LDS_WORDS) * 8 * W::TEAMS;
+    static constexpr int TW_WORDS = 2 * N;       // the block's copy of T[0 .. 2 M): N entries of 16 bytes, behind the teams' images
+    static constexpr size_t LDS_BYTES = size_t(LDS_WORDS * W::TEAMS + TW_WORDS) * 8;
 };
+
+// every thread of the block: copy the twiddle tree into LDS; returns the table (a workgroup barrier inside)
+template <class W>
+__device__ __forceinline__ const double2 *stage_twiddles(const double2 *__restrict__ tw, unsigned char *smem_raw) {
+    double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<u64 *>(smem_raw) + TorusF<W>::LDS_WORDS * W::TEAMS);
+    for (int i = threadIdx.x; i < TorusF<W>::N; i += W::THREADS) dst[i] = tw[i];
+    __syncthreads();
+    return dst;
+}
 
 template <class W>
 __device__ __forceinline__ void pairs_load(u64 (&c)[2 * W::E], const u64 *__restrict__ g, int lane) {
@@ -136,16 +150,38 @@ __device__ __forceinline__ void cmac(double2 &s, const double2 &x, const double2
     s.y = fma(x.x, k.y, fma(x.y, k.x, s.y));
 }
 
+// The decomposition state of a gadget of at most 31 bits (log_b d <= 31: cfg5's 21, the reference's 23) fits one dword once the
+// rounding shift is done: the digit recurrence of decompose.rs:124-134 on 32-bit words -- half the instructions of the u64 form, and the
+// signed digit converts with one v_cvt_f64_i32.  Wider gadgets keep the u64 state.
+template <bool NARROW> struct DigitState;
+template <> struct DigitState<true> {
+    typedef unsigned T;
+    static __device__ __forceinline__ T init(u64 v, const TDecomp &P) { return (unsigned)((v + P.rnd) >> P.rb); }
+    static __device__ __forceinline__ double next(T &c, const TDecomp &P) {
+        const unsigned limb = c & (unsigned)P.mask;
+        c >>= P.log_b;
+        const unsigned carry = (((limb - 1) | c) & limb) >> (P.log_b - 1);
+        c += carry;
+        return (double)(int)(limb - (carry << P.log_b));
+    }
+};
+template <> struct DigitState<false> {
+    typedef u64 T;
+    static __device__ __forceinline__ T init(u64 v, const TDecomp &P) { return tdecomp_init(v, P); }
+    static __device__ __forceinline__ double next(T &c, const TDecomp &P) { return (double)(long long)tdecomp_next(c, P); }  // exact (c64.rs:25 `to_i64() as f64`)
+};
+
 // (sa, sb) <- sum over the 2d limbs of (da, db) of FFT(limb) (.) (row.a, row.b), transformed back: the two halves of the external
 // product (tggsw.rs:100-112, k = 1) as complex slot values, coefficient layout, before rounding
-template <class W>
+template <class W, bool NARROW>
 __device__ __forceinline__ void teamf_gadget(const u64 (&da)[2 * W::E], const u64 (&db)[2 * W::E], const double2 *__restrict__ rows, const TDecomp &P,
                                              int lane, double2 *lds, const ArithC64::K &k, double2 (&sa)[W::E], double2 (&sb)[W::E]) {
     using A = ArithC64;
+    using D = DigitState<NARROW>;
     constexpr int E = W::E;
-    u64 st[2 * E];
+    typename D::T st[2 * E];
 #pragma unroll
-    for (int e = 0; e < 2 * E; ++e) st[e] = tdecomp_init(da[e], P);
+    for (int e = 0; e < 2 * E; ++e) st[e] = D::init(da[e], P);
 #pragma unroll
     for (int e = 0; e < E; ++e) sa[e] = sb[e] = double2{0.0, 0.0};
     KeyRowF<W> kr;
@@ -154,13 +190,13 @@ __device__ __forceinline__ void teamf_gadget(const u64 (&da)[2 * W::E], const u6
     for (int j = 0; j < 2 * P.d; ++j) {
         if (j == P.d) {
 #pragma unroll
-            for (int e = 0; e < 2 * E; ++e) st[e] = tdecomp_init(db[e], P);
+            for (int e = 0; e < 2 * E; ++e) st[e] = D::init(db[e], P);
         }
         double2 x[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {  // signed digits as reals: exact (c64.rs:25 `to_i64() as f64`)
-            x[e].x = (double)(long long)tdecomp_next(st[e], P);
-            x[e].y = (double)(long long)tdecomp_next(st[E + e], P);
+        for (int e = 0; e < E; ++e) {
+            x[e].x = D::next(st[e], P);
+            x[e].y = D::next(st[E + e], P);
         }
         fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
 #pragma unroll
@@ -192,7 +228,8 @@ __device__ __forceinline__ void teamf_cmux(u64 (&ca)[2 * W::E], u64 (&cb)[2 * W:
         for (int e = 0; e < 2 * E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
     }
     double2 sa[E], sb[E];
-    teamf_gadget<W>(da, db, rows, P, lane, reinterpret_cast<double2 *>(lds64), k, sa, sb);
+    if (P.rb >= 33) teamf_gadget<W, true>(da, db, rows, P, lane, reinterpret_cast<double2 *>(lds64), k, sa, sb);  // kernel-uniform
+    else teamf_gadget<W, false>(da, db, rows, P, lane, reinterpret_cast<double2 *>(lds64), k, sa, sb);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const u64 a0 = f64_mod_u64(sa[e].x), a1 = f64_mod_u64(sa[e].y), b0 = f64_mod_u64(sb[e].x), b1 = f64_mod_u64(sb[e].y);
@@ -209,9 +246,9 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_cmux_kernel(u64 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const unsigned ct = blockIdx.x * W::TEAMS + team;
+    const ArithC64::K k = ArithC64::make(stage_twiddles<W>(tw, smem_raw), W::LOG_N);
     if (ct >= batch) return;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS;
-    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
     u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
     u64 ca[2 * E], cb[2 * E];
     pairs_load<W>(ca, ga, lane);
@@ -232,9 +269,9 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const unsigned ct = blockIdx.x * W::TEAMS + team;
+    const ArithC64::K k = ArithC64::make(stage_twiddles<W>(tw, smem_raw), W::LOG_N);
     if (ct >= batch) return;
     u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS;
-    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
     u64 ca[2 * E], cb[2 * E];
     pairs_load<W>(cb, v, lane);
 #pragma unroll
@@ -271,10 +308,10 @@ __global__ __launch_bounds__(W::THREADS) void torusf_key_prepare_kernel(const u6
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = W::lane(), team = W::team();
     const size_t job = size_t(blockIdx.x) * W::TEAMS + team;  // (row, a|b)
+    const ArithC64::K k = ArithC64::make(stage_twiddles<W>(tw, smem_raw), W::LOG_N);
     if (job >= 2 * n_rows) return;
     double2 *lds = reinterpret_cast<double2 *>(reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS);
     const u64 *src = ((job & 1) ? rows_b : rows_a) + (job >> 1) * (2 * M);
-    const ArithC64::K k = ArithC64::make(tw, W::LOG_N);
     double2 x[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
