@@ -46,12 +46,11 @@ struct ArithC64 {
         return r;
     }
     static __device__ __forceinline__ TwReg prep(const TwRaw &r) { return r; }
-    // (X, Y) <- (X + w Y, X - w Y)
+    // (X, Y) <- (X + w Y, X - w Y) in six fused multiply-adds: the sum as two chains, the difference as 2 X - (X + w Y)
     static __device__ __forceinline__ void ct(Elem &X, Elem &Y, const TwReg &w, const K &) {
-        const double tr = fma(-w.y, Y.y, w.x * Y.x), ti = fma(w.y, Y.x, w.x * Y.y);
-        const Elem x = X;
-        X.x = x.x + tr; X.y = x.y + ti;
-        Y.x = x.x - tr; Y.y = x.y - ti;
+        const double sr = fma(-w.y, Y.y, fma(w.x, Y.x, X.x)), si = fma(w.y, Y.x, fma(w.x, Y.y, X.y));
+        Y.x = fma(2.0, X.x, -sr); Y.y = fma(2.0, X.y, -si);
+        X.x = sr; X.y = si;
     }
     // (X, Y) <- (X + Y, (X - Y) conj(w)): |w| = 1, the inverse twiddle is the conjugate (c64.rs:117)
     template <int PH>
