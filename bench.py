@@ -412,6 +412,8 @@ def sharded_secondary(torch, F, dist, dev, local_rank, rank, world, backend):
     # cfg5: BASELINE's 8192 ciphertexts over 8 GPUs = 1024 per GPU
     T = tfhe_setup(torch, F, dev, local_rank, 1024)
     out["tfhe_gate_bootstraps_per_sec"] = job_rate(1024 * world, lambda: T["key"].bootstrap(T["ks_lb"], T["ks_d"], T["ksa"], T["ksb"], T["v"], T["a_raw"], T["b_raw"]), 1)
+    fkey = F.TggswKey(T["t"], T["log_b"], T["d"], T["raw"][0], T["raw"][1], T["n"], fft64=True)  # the reference's f64 FFT product (opt-in mode)
+    out["tfhe_fft64_gate_bootstraps_per_sec"] = job_rate(1024 * world, lambda: fkey.bootstrap(T["ks_lb"], T["ks_d"], T["ksa"], T["ksb"], T["v"], T["a_raw"], T["b_raw"]), 2)
     # cfg4: limbs sharded, L = K = world, a BATCH of 64 ciphertexts per call on the library's sharded entry points (fhe_ckks_shard_*):
     # every rank holds the context and the key and owns q-limb `rank` and p-limb `rank`; ONE all-gather of the p-limb products
     # per batch (RCCL on device memory under nccl, no host synchronisation around it)
