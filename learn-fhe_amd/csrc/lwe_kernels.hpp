@@ -75,45 +75,63 @@ __global__ __launch_bounds__(KS_THREADS) void lwe_key_switch_tiled(const u64 *__
     }
 }
 
-// Wide-output variant (TFHE: 630 output columns, 5120 rows): the grid also splits the columns (blockIdx.y owns KS_THREADS of
-// them), a block owns 8 ciphertexts whose digits are kept as SIGNED BYTES (torus digits with log_b <= 7 lie in [-64, 64]), so a
-// key element fetched from L2 serves 8 ciphertexts and 640 blocks fill the GPU at batch 1024 (the 2-ciphertext tile above was
-// L2-bandwidth bound there: 2.3 ms per 1024, 4 % of a gate).
+// Wide-output variant (TFHE: 630 output columns, 5120 rows; torus digits with log_b <= 7 lie in [-64, 64]: bytes).  The grid splits the
+// ciphertexts (TILE per block: a key element fetched from L2 serves all of them), the output columns (KS_THREADS per block) AND the input
+// coefficients (`chunk` per block, all d digits of each); a block adds its partial sums to the outputs with 64-bit atomics -- additions
+// mod 2^64 commute, so the result is the same bits in any order.  Round 2's form walked all 5120 rows in one block: 640 blocks of two
+// waves at batch 1024 (2.5 blocks per CU, four key loads in flight per wave: 64 % of its cycles parked, 1.86 ms per 1024 ciphertexts --
+// 15 % of a gate in the fft64 mode); here the grid is Z times larger and the digit image Z times smaller.  Digits are stored with +128 (unsigned bytes), so
+// a term is ONE v_mad_u64_u32 per output dword; the offset leaves as 128 x (the sum of the key column), taken once per block.
+// out_a, out_b must be ZERO before the launch.
 template <int TILE>
-__global__ __launch_bounds__(KS_THREADS) void tlwe_key_switch_wide(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in,
-                                                                   unsigned n_out, unsigned batch, const u64 *__restrict__ ksk_a,
-                                                                   const u64 *__restrict__ ksk_b, TDecomp P, u64 *__restrict__ out_a,
-                                                                   u64 *__restrict__ out_b) {
+__global__ __launch_bounds__(KS_THREADS) void tlwe_key_switch_split(const u64 *__restrict__ ct_a, const u64 *__restrict__ ct_b, unsigned n_in,
+                                                                    unsigned n_out, unsigned batch, const u64 *__restrict__ ksk_a,
+                                                                    const u64 *__restrict__ ksk_b, TDecomp P, u64 *__restrict__ out_a,
+                                                                    u64 *__restrict__ out_b, unsigned chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    signed char *dig = reinterpret_cast<signed char *>(smem_raw);  // [rows][TILE]
-    const unsigned ct0 = blockIdx.x * TILE;
-    const unsigned rows = n_in * P.d;
-    for (unsigned idx = threadIdx.x; idx < n_in * TILE; idx += KS_THREADS) {
-        const unsigned c = idx / n_in, i = idx - c * n_in;
+    unsigned char *dig = smem_raw;  // [d][chunk][TILE]
+    const unsigned ct0 = blockIdx.x * TILE, i0 = blockIdx.z * chunk;
+    const unsigned ni = min(chunk, n_in - i0);
+    for (unsigned idx = threadIdx.x; idx < ni * TILE; idx += KS_THREADS) {
+        const unsigned c = idx / ni, ii = idx - c * ni;
         const bool live = ct0 + c < batch;
-        u64 st = live ? tdecomp_init(ct_a[size_t(ct0 + c) * n_in + i], P) : 0;
-        for (int j = 0; j < P.d; ++j) dig[(size_t(j) * n_in + i) * TILE + c] = live ? (signed char)(long long)tdecomp_next(st, P) : 0;
+        u64 st = live ? tdecomp_init(ct_a[size_t(ct0 + c) * n_in + i0 + ii], P) : 0;
+        for (int j = 0; j < P.d; ++j) dig[(size_t(j) * chunk + ii) * TILE + c] = (unsigned char)(128 + (live ? (int)(long long)tdecomp_next(st, P) : 0));
     }
     __syncthreads();
     const unsigned col = blockIdx.y * KS_THREADS + threadIdx.x;
     if (col > n_out) return;
-    u64 acc[TILE];
+    unsigned lo[TILE], hi[TILE];  // the low and the high dword of each sum, carried apart
 #pragma unroll
-    for (int c = 0; c < TILE; ++c) acc[c] = 0;
+    for (int c = 0; c < TILE; ++c) lo[c] = hi[c] = 0;
+    u64 ksum = 0;
     const u64 *kp = col < n_out ? ksk_a + col : ksk_b;
     const size_t stride = col < n_out ? n_out : 1;
+    for (int j = 0; j < P.d; ++j) {
+        const u64 *kr = kp + (size_t(j) * n_in + i0) * stride;
+        const unsigned char *dj = dig + size_t(j) * chunk * TILE;
 #pragma unroll 4
-    for (unsigned row = 0; row < rows; ++row) {
-        const u64 kv = kp[row * stride];
-        const signed char *dr = dig + size_t(row) * TILE;
+        for (unsigned ii = 0; ii < ni; ++ii) {
+            const u64 kv = kr[ii * stride];
+            ksum += kv;
+            const unsigned klo = (unsigned)kv, khi = (unsigned)(kv >> 32);
+            const unsigned char *dr = dj + size_t(ii) * TILE;
 #pragma unroll
-        for (int c = 0; c < TILE; ++c) acc[c] += kv * (u64)(long long)dr[c];  // wrapping: arithmetic mod 2^64
+            for (int c = 0; c < TILE; ++c) {
+                const unsigned dg = dr[c];
+                const u64 t = (u64)klo * dg + lo[c];  // < 2^40 + 2^32: the carry into the high dword rides in t's upper half
+                lo[c] = (unsigned)t;
+                hi[c] += khi * dg + (unsigned)(t >> 32);
+            }
+        }
     }
+    const u64 off = ksum << 7;  // 128 x sum of the key entries
 #pragma unroll
     for (int c = 0; c < TILE; ++c) {
         if (ct0 + c >= batch) continue;
-        if (col < n_out) out_a[size_t(ct0 + c) * n_out + col] = acc[c];
-        else out_b[ct0 + c] = acc[c] + ct_b[ct0 + c];
+        u64 v = (((u64)hi[c] << 32) | lo[c]) - off;
+        if (col < n_out) atomicAdd(reinterpret_cast<unsigned long long *>(out_a + size_t(ct0 + c) * n_out + col), (unsigned long long)v);
+        else atomicAdd(reinterpret_cast<unsigned long long *>(out_b + ct0 + c), (unsigned long long)(v + (blockIdx.z == 0 ? ct_b[ct0 + c] : 0)));
     }
 }
 

@@ -574,15 +574,21 @@ int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t 
         mb(ct_b, batch, mem, true, st), moa(out_a, n_out * batch, mem, false, st), mob(out_b, batch, mem, false, st);
     if (mka.rc | mkb.rc | ma.rc | mb.rc | moa.rc | mob.rc) return FHE_ERR_HIP;
     const int tile = P.log_b <= 31 ? fhe::ks_tile(batch, rows) : 0;  // the tiled kernel keeps digits as 32-bit words
-    constexpr int WIDE_TILE = 8;
-    if (P.log_b <= 7 && n_out >= 256 && batch >= 64 && rows * WIDE_TILE <= 96 * 1024 && batch < (size_t(1) << 31)) {
-        // many output columns: split them over the grid, 8 ciphertexts per block, byte digits (lwe_kernels.hpp)
-        const size_t lds = rows * WIDE_TILE;
-        auto k = fhe::tlwe_key_switch_wide<WIDE_TILE>;
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)((batch + WIDE_TILE - 1) / WIDE_TILE), (unsigned)((n_out + 1 + fhe::KS_THREADS - 1) / fhe::KS_THREADS)),
-                           dim3(fhe::KS_THREADS), lds, st, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_in, (unsigned)n_out,
-                           (unsigned)batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d);
+    constexpr int WIDE_TILE = 16;
+    if (P.log_b <= 7 && n_out >= 256 && batch >= 64 && batch < (size_t(1) << 31) && n_in < (size_t(1) << 31)) {
+        // many output columns: ciphertext tiles x column blocks x input-coefficient chunks, partial sums added atomically (lwe_kernels.hpp)
+        const unsigned tiles = (unsigned)((batch + WIDE_TILE - 1) / WIDE_TILE), colb = (unsigned)((n_out + 1 + fhe::KS_THREADS - 1) / fhe::KS_THREADS);
+        // enough blocks for ~8 waves per SIMD, chunks of at least 64 coefficients
+        unsigned z = (unsigned)((size_t(16) * fhe::current_cu_count() + size_t(tiles) * colb - 1) / (size_t(tiles) * colb));
+        const unsigned zmax = (unsigned)((n_in + 63) / 64);
+        z = z < 1 ? 1 : (z > zmax ? zmax : z);
+        const unsigned chunk = (unsigned)((n_in + z - 1) / z);
+        z = (unsigned)((n_in + chunk - 1) / chunk);
+        HIP_TRY(hipMemsetAsync(moa.d, 0, n_out * batch * sizeof(u64), st));
+        HIP_TRY(hipMemsetAsync(mob.d, 0, batch * sizeof(u64), st));
+        const size_t lds = size_t(P.d) * chunk * WIDE_TILE;
+        hipLaunchKernelGGL(fhe::tlwe_key_switch_split<WIDE_TILE>, dim3(tiles, colb, z), dim3(fhe::KS_THREADS), lds, st, (const u64 *)ma.d, (const u64 *)mb.d,
+                           (unsigned)n_in, (unsigned)n_out, (unsigned)batch, (const u64 *)mka.d, (const u64 *)mkb.d, P, moa.d, mob.d, chunk);
     } else if (tile && batch < (size_t(1) << 31)) {
         if (fhe::launch_key_switch_tiled(fhe::KsTorus{P}, ma.d, mb.d, n_in, n_out, batch, mka.d, mkb.d, moa.d, mob.d, tile, st)) return FHE_ERR_HIP;
     } else {
