@@ -581,7 +581,10 @@ int fhe_tlwe_key_switch(int log_b, int d, const uint64_t *ksk_a, const uint64_t 
         // enough blocks for ~8 waves per SIMD, chunks of at least 64 coefficients
         unsigned z = (unsigned)((size_t(16) * fhe::current_cu_count() + size_t(tiles) * colb - 1) / (size_t(tiles) * colb));
         const unsigned zmax = (unsigned)((n_in + 63) / 64);
-        z = z < 1 ? 1 : (z > zmax ? zmax : z);
+        const size_t chunk_cap = (48 * 1024) / (size_t(P.d) * WIDE_TILE);  // the digit image of a block stays below 48 KiB of LDS
+        const unsigned zmin = (unsigned)((n_in + chunk_cap - 1) / chunk_cap);
+        z = z > zmax ? zmax : z;
+        z = z < zmin ? zmin : (z < 1 ? 1 : z);
         const unsigned chunk = (unsigned)((n_in + z - 1) / z);
         z = (unsigned)((n_in + chunk - 1) / chunk);
         HIP_TRY(hipMemsetAsync(moa.d, 0, n_out * batch * sizeof(u64), st));

@@ -206,6 +206,24 @@ def test_tlwe_key_switch_tiles(fhe, torch_cuda):
             assert L(ha[i]) == ya and int(hb[i]) == yb, (batch, i)
 
 
+def test_tlwe_key_switch_split_grid_shapes(fhe, cref, torch_cuda):
+    """The wide TLWE key switch splits ciphertexts x output columns x input coefficients over the grid and adds partial sums with 64-bit
+    atomics (csrc/lwe_kernels.hpp `tlwe_key_switch_split`): every split the host picks -- small batches (many coefficient chunks), ragged
+    tiles, a batch large enough that one block keeps ALL coefficients (the digit image near its LDS cap) -- gives the oracle's bits."""
+    n_in, n_out, log_b, d = 512, 300, 4, 5
+    rng = np.random.Generator(np.random.PCG64(77))
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)  # noqa: E731
+    ksa, ksb = r64(n_in * d, n_out), r64(n_in * d)
+    dka, dkb = dev(torch_cuda, ksa), dev(torch_cuda, ksb)
+    for batch in (64, 77, 1000, 30000):
+        ca, cb = r64(batch, n_in), r64(batch)
+        oa, ob = fhe.tlwe_key_switch(log_b, d, dka, dkb, dev(torch_cuda, ca), dev(torch_cuda, cb), n_in, n_out)
+        ha, hb = host(oa).reshape(batch, n_out), host(ob).reshape(batch)
+        for i in sorted({0, 1, 15, 16, batch // 2, batch - 1}):
+            wa, wb = cref.tlwe_key_switch(log_b, d, ksa, ksb, ca[i], int(cb[i]))
+            assert np.array_equal(ha[i], wa) and int(hb[i]) == wb, (batch, i)
+
+
 def test_blind_rotate_large_batch_is_deterministic(fhe, torch_cuda):
     """cfg5 ring (N = 1024, base 2^7, d = 3), 1024 ciphertexts: every SIMD busy with multi-wave teams sharing LDS images; two runs
     agree bit for bit, and a sample agrees with the same ciphertexts run as a small batch"""
