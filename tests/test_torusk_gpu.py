@@ -209,3 +209,30 @@ def test_rank2_gate_bootstrap_decode_level(fhe, torch_cuda):
         for m in range(p):
             mu = ((P.tlwe_phase(zh, L(host(oa)[m]), int(host(ob)[m])) + (1 << (log_delta - 1))) % P.M64) >> log_delta
             assert mu % p == f(m) % p, (li, m, mu)
+
+
+def test_new_entries_status_codes(fhe, torch_cuda):
+    """Where the reference would panic or has nothing to do: empty batches, foreign keys, indices past the key, rings and ranks outside the
+    build, a gadget whose exact products would not fit the two primes, aliasing that the entry cannot honour."""
+    import ctypes as C
+    lib = fhe.lib()
+    t, t2 = fhe.TorusContext(), fhe.TorusContext()
+    n, k, log_b, d = 64, 2, 8, 2
+    rows = np.zeros((1, (k + 1) * d, k + 1, n), dtype=np.uint64)
+    key = fhe.TggswKeyK(t, k, log_b, d, rows, n)
+    ct = np.zeros((1, k + 1, n), dtype=np.uint64)
+    p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    H = C.c_void_p()
+    assert lib.fhe_tggswk_external_product(t.handle, key._h, 0, None, 0, 0, None) == 0                      # empty batch
+    assert lib.fhe_tggswk_external_product(t.handle, key._h, 1, p(ct), 1, 0, None) == 1                     # index past the key
+    assert lib.fhe_tggswk_external_product(t2.handle, key._h, 0, p(ct), 1, 0, None) == 1                    # key of another context
+    assert lib.fhe_tggswk_prepare(t.handle, 9, log_b, d, p(rows), n, 1, 0, C.byref(H)) == 6                 # rank above the build's 8
+    assert lib.fhe_tggswk_prepare(t.handle, 0, log_b, d, p(rows), n, 1, 0, C.byref(H)) == 1                 # rank 0
+    assert lib.fhe_tggswk_prepare(t.handle, k, 62, 1, p(rows), n, 1, 0, C.byref(H)) == 6                    # (k+1) d n 2^(62+log_b) >= 2^118
+    assert lib.fhe_tggswk_prepare(t.handle, k, log_b, d, p(rows), 48, 1, 0, C.byref(H)) == 1                # n not a power of two
+    assert lib.fhe_tglwek_rotate(p(ct), k, n, 3, p(ct), 1, 0, None) == 1                                    # out == in
+    assert lib.fhe_tglwek_sample_extract(p(ct), k, n, n, p(ct), p(ct), 1, 0, None) == 1                     # index >= n
+    ra = np.zeros((1, 2 * d, 128), dtype=np.uint64)
+    assert lib.fhe_tggsw_prepare_fft64(t.handle, log_b, d, p(ra), p(ra), 128, 1, 0, C.byref(H)) == 6        # fft64 rings: 256 .. 2048
+    assert lib.fhe_tggsw_prepare_fft64(t.handle, 0, d, p(ra), p(ra), 256, 1, 0, C.byref(H)) == 1            # log_b = 0
+    assert not H.value
