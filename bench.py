@@ -244,8 +244,8 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=3, verify=True):
     """BASELINE config 5, one GPU's share (8192 / 8 = 1024 ciphertexts): TFHE gate bootstrap (scheme/tfhe/src/
     bootstrapping.rs:78-104) at N = 2^10, k = 1, through the single-call gate fhe_tfhe_bootstrap: mod switch, n_lwe = 630 CMUXes
     (base 2^7, d = 3 -- the reference ships no N = 2^10 parameter set; these are the usual ones for that ring), sample extract,
-    TLWE key switch (base 2^4, d = 5 as in the reference's test).  Exact torus arithmetic (CRT over three 30-bit primes at this
-    shape), uniform-random keys."""
+    TLWE key switch (base 2^4, d = 5 as in the reference's test).  Exact torus arithmetic (at this shape: key words cut into three
+    pieces whose products with the digits are exact in f64 transforms -- DESIGN.md section 9), uniform-random keys."""
     S = tfhe_setup(torch, F, dev, local_rank, batch)
     dt = _timeit(torch, lambda: S["key"].bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"]), reps)
     out = {"workload": "cfg5 (one GPU's share): TFHE gate bootstrap N=2^10 k=1 n_lwe=630 (7,3) ks (4,5), batch=%d" % batch,
@@ -262,13 +262,13 @@ def tfhe_bench(torch, F, dev, local_rank, batch=1024, reps=3, verify=True):
         out["verified"] = bool(all(np.array_equal(ha[i], ea[j]) and int(hb[i]) == int(eb[j]) for j, i in enumerate(pick)))
         out["verification"] = "gate bootstrap at batch %d: ciphertexts 0 and %d bit-equal to the exact CPU oracle" % (batch, batch - 1)
     cmux_bytes = (4 * S["d"] + 4) * 8 * S["n"]  # as an RGSW external product: ct in + 2d rows x 2 + ct out
-    out["roofline"] = roof(batch / dt, S["n_lwe"] * cmux_bytes, "torus30_blind_rotate_kernel<TorusRing30<10>> (630 CMUXes in one launch)",
+    out["roofline"] = roof(batch / dt, S["n_lwe"] * cmux_bytes, "torusx3_blind_rotate_kernel<WaveRing<9,2>> (630 CMUXes in one launch; exact: key words in three pieces through f64 transforms)",
                            "%d CMUXes x %d B per gate (TLWE key switch not counted); TGGSW rows are cache hits: bound by VALU issue" % (S["n_lwe"], cmux_bytes))
     # the same gate through the f64 FFT product the reference itself computes with (util/src/ring/fft/c64.rs; fhe_tggsw_prepare_fft64):
     # floating point, so NOT bit-exact -- checked against the exact mode's accumulators within the reference's own error bound
     fkey = F.TggswKey(S["t"], S["log_b"], S["d"], S["raw"][0], S["raw"][1], S["n"], fft64=True)
     fdt = _timeit(torch, lambda: fkey.bootstrap(S["ks_lb"], S["ks_d"], S["ksa"], S["ksb"], S["v"], S["a_raw"], S["b_raw"]), reps)
-    f = {"mode": "fft64: one pass of N/2-point complex f64 transforms per CMUX (the reference's algorithm) instead of three passes of 30-bit NTTs",
+    f = {"mode": "fft64: 2d + 2 N/2-point complex f64 transforms per CMUX on the key words as they are (the reference's algorithm) where the exact mode runs 4d + 6 on three key pieces",
          "gate_bootstraps_per_sec": batch / fdt, "vs_exact_mode": dt / fdt}
     if verify:
         # ONE CMUX over the whole batch in both modes (the exact mode's gate is checked against the oracle above): every coefficient within

@@ -52,7 +52,7 @@ int fhe_trim(void);
  * result.  Each is read ONCE from the environment (FHE_RING_<NAME>) and afterwards only through this call: the library never calls
  * getenv on a call path.  Names: "NO_EDGE" (key switch at N = 2^15 on whole transforms), "NO_LIMB_MAJOR" (linear dispatch order over
  * several moduli), "NO_W12" (2^12 / 2^13 rings on the generic kernels), "NO_FUSED_MUL" (ring product as forward + multiplying
- * inverse), "SMALL_BATCH" (FHEW: 4 coefficients per lane up to this batch, 8 above; -1 = the library's rule), "NO_PACKED_DIGITS" (TFHE blind
+ * inverse), "SMALL_BATCH" (FHEW: 4 coefficients per lane up to this batch, 8 above; -1 = the library's rule), "NO_F64_EXACT" (TFHE: eligible keys on the three-prime integer path instead of the three-piece f64 one), "NO_PACKED_DIGITS" (TFHE blind
  * rotation: digits decomposed once per prime instead of once per CMUX).  Unknown name:
  * FHE_ERR_INVALID. */
 int fhe_set_option(const char *name, long value);
@@ -283,7 +283,10 @@ int fhe_torus_decompose(int log_b, int d, const uint64_t *in, size_t n, size_t p
  * n * 2^(64 + log_bound_b) < 2^118 (gadget digits, small secrets: what the reference's FFT product is used for). */
 int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int log_bound_b, size_t n, size_t batch, fhe_mem mem,
                   void *stream);
-/* `count` TGGSW ciphertexts (scheme/tfhe/src/tggsw.rs:44-88): rows_a / rows_b [count][2d][n].  n = 256 .. 2048. */
+/* `count` TGGSW ciphertexts (scheme/tfhe/src/tggsw.rs:44-88): rows_a / rows_b [count][2d][n].  n = 256 .. 2048.  The exact products run on
+ * one of three forms chosen from the gadget: key words cut into three signed pieces through f64 transforms whose rounded results are exact
+ * (2d n 2^log_b <= 2^23, base <= 2^7: BASELINE config 5), three 30-bit NTT primes (2d n 2^(62 + log_b) < 2^88), two 60-bit primes
+ * (< 2^118; beyond that FHE_ERR_UNSUPPORTED).  All three give the same bits. */
 int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
                       fhe_mem mem, fhe_tggsw_key **out);
 void fhe_tggsw_key_destroy(fhe_tggsw_key *key);

@@ -100,8 +100,8 @@ inline hipMemPool_t private_pool(int dev) {
 // need no second build.  None changes a result.  Each is read from the environment ONCE (FHE_RING_<NAME>, when the library first
 // looks at any of them) and afterwards only changes through fhe_set_option(): no getenv on any call path.
 namespace fhe {
-enum Opt { OPT_NO_EDGE = 0, OPT_NO_LIMB_MAJOR, OPT_NO_W12, OPT_NO_FUSED_MUL, OPT_SMALL_BATCH, OPT_NO_PACKED_DIGITS, OPT_COUNT };
-inline const char *const OPT_NAMES[OPT_COUNT] = {"NO_EDGE", "NO_LIMB_MAJOR", "NO_W12", "NO_FUSED_MUL", "SMALL_BATCH", "NO_PACKED_DIGITS"};
+enum Opt { OPT_NO_EDGE = 0, OPT_NO_LIMB_MAJOR, OPT_NO_W12, OPT_NO_FUSED_MUL, OPT_SMALL_BATCH, OPT_NO_PACKED_DIGITS, OPT_NO_F64_EXACT, OPT_COUNT };
+inline const char *const OPT_NAMES[OPT_COUNT] = {"NO_EDGE", "NO_LIMB_MAJOR", "NO_W12", "NO_FUSED_MUL", "SMALL_BATCH", "NO_PACKED_DIGITS", "NO_F64_EXACT"};
 struct Options {
     std::atomic<long> v[OPT_COUNT];
     Options() {

@@ -100,6 +100,18 @@ int launch_cmux(const fhe_torus_ctx *t, const fhe_tggsw_key *key, size_t index, 
         HIP_TRY(hipGetLastError());
         return FHE_OK;
     }
+    if (key->d_rowsx3) {  // exact, three key pieces through f64 transforms
+        const double2 *xrows = key->d_rowsx3 + index * (per / 2) * 3;
+        TORUS_DISPATCH(key->log_n, {
+            typedef TorusRingF<LN> WR;
+            const size_t lds = fhe::TorusX3<WR>::lds_bytes(2 * key->d);
+            if (set_lds((fhe::torusx3_cmux_kernel<WR, TF_MIN_WAVES>), lds) != FHE_OK) return FHE_ERR_HIP;
+            hipLaunchKernelGGL((fhe::torusx3_cmux_kernel<WR, TF_MIN_WAVES>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), lds, st, a, b,
+                               (unsigned)batch, xrows, key->P, rot, rot_stride, (const double2 *)t->d_twf);
+        });
+        HIP_TRY(hipGetLastError());
+        return FHE_OK;
+    }
     if (key->d_rows30) {  // three 30-bit primes
         const size_t plane = key->count * per;
         TORUS_DISPATCH(key->log_n, {
@@ -281,6 +293,7 @@ void fhe_tggsw_key_destroy(fhe_tggsw_key *k) {
         if (k->d_rows[0]) (void)hipFree(k->d_rows[0]);
         if (k->d_rows30) (void)hipFree(k->d_rows30);
         if (k->d_rowsf) (void)hipFree(k->d_rowsf);
+        if (k->d_rowsx3) (void)hipFree(k->d_rowsx3);
     }
     delete k;
 }
@@ -301,6 +314,11 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     const int bound_bits = ilog2((size_t)2 * d) + 1 + log_n + 62 + log_b;
     if (bound_bits > 118) return FHE_ERR_UNSUPPORTED;              // two 60-bit primes: P / 2 ~ 2^118.9
     const bool use30 = bound_bits <= 88 && log_b <= 28;            // three 30-bit primes: P / 2 ~ 2^88.9 (torus30_kernels.hpp)
+    // exact through f64 transforms of three key pieces (torusf_kernels.hpp: TorusX3): 2d N 2^log_b <= 2^23 keeps the rounding error a factor
+    // 30 inside 1/2; digits must be bytes (log_b <= 7) and their state a dword (log_b d <= 31), at most 16 limbs (the digit area in LDS);
+    // N <= 1024 (four slots per lane at most)
+    const bool usex3 = (size_t(2 * d) << (log_n + log_b)) <= (size_t(1) << 23) && log_b <= 7 && log_b * d <= 31 && 2 * d <= 16 && log_n <= 10 &&
+                       fhe::opt(fhe::OPT_NO_F64_EXACT) == 0;
     DeviceGuard guard(t->device);
     if (!guard.ok) return FHE_ERR_HIP;
     const size_t rows = count * 2 * d, words = rows * n;
@@ -313,7 +331,18 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     if (e == hipSuccess) e = hipMemcpyAsync(src + words, rows_b, words * sizeof(u64), kind, st);
     rc = e == hipSuccess ? FHE_OK : FHE_ERR_HIP;
     if (e != hipSuccess) g_last_hip = (int)e;
-    if (rc == FHE_OK && use30) {
+    double2 *dstx3 = nullptr;
+    if (rc == FHE_OK && usex3) {
+        if (hipMalloc((void **)&dstx3, 6 * rows * (n / 2) * sizeof(double2)) != hipSuccess) rc = FHE_ERR_HIP;
+        if (rc == FHE_OK) {
+            TORUS_DISPATCH(log_n, {
+                typedef TorusRingF<LN> WR;
+                hipLaunchKernelGGL(fhe::torusx3_key_prepare_kernel<WR>, dim3((unsigned)((6 * rows + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
+                                   fhe::TorusF<WR>::LDS_BYTES, st, (const u64 *)src, (const u64 *)(src + words), rows, (const double2 *)t->d_twf, dstx3);
+            });
+            if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+        }
+    } else if (rc == FHE_OK && use30) {
         if (hipMalloc((void **)&dst30, 3 * 2 * words * sizeof(unsigned)) != hipSuccess) rc = FHE_ERR_HIP;
         for (int pi = 0; pi < 3 && rc == FHE_OK; ++pi) {
             TORUS_DISPATCH(log_n, {
@@ -344,11 +373,11 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     if (hipStreamSynchronize(st) != hipSuccess && rc == FHE_OK) rc = FHE_ERR_HIP;
     (void)hipFree(src);
     if (tmp) (void)hipFree(tmp);
-    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); return rc; }
+    if (rc != FHE_OK) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); if (dstx3) (void)hipFree(dstx3); return rc; }
     fhe_tggsw_key *k = new (std::nothrow) fhe_tggsw_key();
-    if (!k) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); return FHE_ERR_INVALID; }
+    if (!k) { if (dst) (void)hipFree(dst); if (dst30) (void)hipFree(dst30); if (dstx3) (void)hipFree(dstx3); return FHE_ERR_INVALID; }
     k->t = t; k->log_n = log_n; k->log_b = log_b; k->d = d; k->count = count; k->P = P;
-    k->d_rows[0] = dst; k->d_rows[1] = dst ? dst + 2 * words : nullptr; k->d_rows30 = dst30;
+    k->d_rows[0] = dst; k->d_rows[1] = dst ? dst + 2 * words : nullptr; k->d_rows30 = dst30; k->d_rowsx3 = dstx3;
     *out = k;
     return FHE_OK;
 }
@@ -491,6 +520,15 @@ int fhe_tfhe_blind_rotate(const fhe_torus_ctx *t, const fhe_tggsw_key *brk, cons
             hipLaunchKernelGGL((fhe::torusf_blind_rotate_kernel<WR, TF_MIN_WAVES>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS),
                                fhe::TorusF<WR>::LDS_BYTES, st, (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe, (unsigned)batch,
                                (const double2 *)brk->d_rowsf, brk->P, (const double2 *)t->d_twf, moa.d, mob.d);
+        });
+    } else if (brk->d_rowsx3) {  // exact, three key pieces through f64 transforms
+        TORUS_DISPATCH(brk->log_n, {
+            typedef TorusRingF<LN> WR;
+            const size_t lds = fhe::TorusX3<WR>::lds_bytes(2 * brk->d);
+            if (set_lds((fhe::torusx3_blind_rotate_kernel<WR, TF_MIN_WAVES>), lds) != FHE_OK) return FHE_ERR_HIP;
+            hipLaunchKernelGGL((fhe::torusx3_blind_rotate_kernel<WR, TF_MIN_WAVES>), dim3((unsigned)((batch + WR::TEAMS - 1) / WR::TEAMS)), dim3(WR::THREADS), lds, st,
+                               (const u64 *)mv.d, (const u64 *)ma.d, (const u64 *)mb.d, (unsigned)n_lwe, (unsigned)batch, (const double2 *)brk->d_rowsx3, brk->P,
+                               (const double2 *)t->d_twf, moa.d, mob.d);
         });
     } else if (brk->d_rows30) {  // three 30-bit primes
         const size_t plane = brk->count * size_t(2 * brk->d) * 2 * n;

@@ -28,6 +28,7 @@ struct fhe_tggsw_key {
     u64 *d_rows[2] = {nullptr, nullptr};  // per prime: [count][2d][2][N] evaluation domain, key_perm layout
     unsigned *d_rows30 = nullptr;         // 30-bit path: [3 primes][count][2d][2][N] Montgomery residues, key_perm30 layout
     double2 *d_rowsf = nullptr;           // fft64 mode: [count][2d][2][N / 2] complex evaluations (torusf_kernels.hpp)
+    double2 *d_rowsx3 = nullptr;          // exact through f64 transforms: [count][2d][2][3 pieces][N / 2] complex evaluations (torusf_kernels.hpp)
     fhe::TDecomp P{};
 };
 

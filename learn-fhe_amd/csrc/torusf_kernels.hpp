@@ -298,6 +298,233 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
 // (17.3 k against 26.5 k at batch 256: one ciphertext per block leaves a CU two waves) -- half the LDS traffic and two barriers per CMUX
 // instead of fifty, but eight-slot transforms with two waves per SIMD have nothing to hide their dependency chains behind.
 
+// ---- EXACT products through the same transforms: key words cut into three signed pieces --------------------------------------------
+// A key word k (signed 64 bits) = k0 + k1 2^22 + k2 2^43 with |k0| <= 2^21, |k1|, |k2| <= 2^20.  The product of a digit polynomial
+// (|digit| <= 2^(log_b - 1)) with ONE piece has coefficients below N 2^(log_b + 20): integers that an f64 transform of this size
+// reproduces with an error far below 1/2, so rounding recovers them EXACTLY, and the three rounded products recombine to the
+// exact product mod 2^64 with shifts and wrapping adds.  Error bound (Percival 2003 for FFT convolutions: |err| <= ||x||_2 ||y||_2
+// ((1 + eps)^(3 n) (1 + eps sqrt 5)^(3 n + 1) (1 + beta)^(3 n) - 1), n = log2 of the transform size, beta ~ eps the twiddle error:
+// <= 130 eps for n <= 10): ||digits||_2 <= sqrt(N) 2^(log_b - 1), ||piece||_2 <= sqrt(N) 2^21, 2d products summed:
+// err <= 2d N 2^(log_b + 20) 130 2^-53.  The host takes this path only while 2d N 2^log_b <= 2^23 (err <= 0.016 at the limit: a factor
+// 30 inside 1/2; cfg5: 2d N 2^log_b = 2^19.6, err <= 1.5e-3): the result is the exact oracle's, bit for bit, and the whole-gate and
+// extreme-operand tests of tests/test_torus_gpu.py hold it to that.  One CMUX = the digits once (bytes, parked in LDS), then per
+// output (a, b): 2d forward transforms, 3 x 2d multiply-accumulates per slot, three inverse transforms, cheap roundings (|value| <
+// 2^40: the magic-constant trick) and the recombination: 12 + 6 half-size complex transforms where the three-prime path runs 24
+// full-size 30-bit ones.  Measured and dropped: both outputs in ONE pass over the limbs (six sums per slot, the accumulator parked in
+// LDS, twiddles from HBM for want of LDS: 6 + 6 transforms, 192 registers) -- 32.2 k gates/s at cfg5 against 34.1 k for the two passes
+// (25.4 k against 31.2 k at batch 4096): six key streams per slot consumed the moment they are requested cost more than six transforms.
+template <class W>
+struct TorusX3 {
+    static constexpr int M = W::N, N = 2 * W::N, E = W::E;
+    static constexpr int IMG_WORDS = 2 * W::PN;
+    static constexpr int DIG_WORDS_PER_LIMB = W::TEAM;          // 2 dwords per lane and limb (E <= 4 digits each) = TEAM 8-byte words
+    static __host__ __device__ constexpr int lds_words(int limbs) { return IMG_WORDS + limbs * DIG_WORDS_PER_LIMB; }  // per team
+    static __host__ __device__ constexpr size_t lds_bytes(int limbs) { return size_t(lds_words(limbs) * W::TEAMS + 2 * N) * 8; }  // + the twiddle tree
+    static_assert(W::E <= 4, "digits of a lane's E slots are packed into one dword");
+};
+
+__device__ __forceinline__ void key_pieces(u64 k, double (&p)[3]) {
+    const long long v = (long long)k;
+    const long long p0 = (long long)((u64)v << 42) >> 42;   // low 22 bits, sign extended
+    const long long rem = (v - p0) >> 22;                    // exact
+    const long long p1 = (long long)((u64)rem << 43) >> 43;  // low 21 bits, sign extended
+    const long long p2 = (rem - p1) >> 21;                   // |p2| <= 2^20
+    p[0] = (double)p0; p[1] = (double)p1; p[2] = (double)p2;
+}
+
+// |v| < 2^50, v within 1/2 of an integer: that integer, through the mantissa of v + 1.5 2^52
+__device__ __forceinline__ long long round_small(double v) {
+    const long long bits = __double_as_longlong(v + 6755399441055744.0);
+    return (bits & 0xfffffffffffffll) - (1ll << 51);
+}
+
+// the 2d x 2E digits of one CMUX, computed once: dig[(limb * 2 + h) * TEAM + lane] packs the E digits of the lane's slots (h = 0:
+// coefficients k_e, h = 1: coefficients k_e + M) as signed bytes
+template <class W>
+__device__ __forceinline__ void park_digits_x3(const u64 (&da)[2 * W::E], const u64 (&db)[2 * W::E], const TDecomp &P, int lane, unsigned *dig) {
+    constexpr int E = W::E;
+    const unsigned mask = (unsigned)P.mask;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        unsigned st[2 * E];  // log_b d <= 31 on this path: the state fits a dword after the rounding shift
+#pragma unroll
+        for (int e = 0; e < 2 * E; ++e) st[e] = (unsigned)(((half ? db[e] : da[e]) + P.rnd) >> P.rb);
+#pragma unroll 1
+        for (int j = 0; j < P.d; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned w = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    unsigned &c = st[h * E + e];
+                    const unsigned limb = c & mask;
+                    c >>= P.log_b;
+                    const unsigned carry = (((limb - 1) | c) & limb) >> (P.log_b - 1);
+                    c += carry;
+                    w |= ((limb - (carry << P.log_b)) & 0xffu) << (8 * e);
+                }
+                dig[((half * P.d + j) * 2 + h) * W::TEAM + lane] = w;
+            }
+        }
+    }
+}
+
+// one output (o = 0: a, 1: b) of the external product from the parked digits: out[e], out[E + e] = the exact coefficients mod 2^64
+template <class W>
+__device__ __forceinline__ void x3_output(const unsigned *dig, const double2 *__restrict__ rows, int d2, int o, int lane, double2 *lds, const ArithC64::K &k,
+                                          u64 (&out)[2 * W::E]) {
+    using A = ArithC64;
+    constexpr int E = W::E, M = W::N;
+    double2 s0[E], s1[E], s2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s0[e] = s1[e] = s2[e] = double2{0.0, 0.0};
+    const double2 *row = rows + size_t(o) * 3 * M;  // rows: [limb][a | b][piece][M]
+#pragma unroll 1
+    for (int j = 0; j < d2; ++j) {
+        const unsigned wl = dig[(j * 2 + 0) * W::TEAM + lane], wh = dig[(j * 2 + 1) * W::TEAM + lane];
+        double2 x[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            x[e].x = (double)((int)(wl << (24 - 8 * e)) >> 24);
+            x[e].y = (double)((int)(wh << (24 - 8 * e)) >> 24);
+        }
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int slot = e * W::TEAM + lane;
+            cmac(s0[e], x[e], row[slot]);
+            cmac(s1[e], x[e], row[M + slot]);
+            cmac(s2[e], x[e], row[2 * M + slot]);
+        }
+        row += 6 * M;
+    }
+    inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(s0, lane, nullptr, lds, true, k);
+    inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(s1, lane, nullptr, lds, true, k);
+    inv_run<A, typename W::C, W::LOG_N, W::LOG_E, W::LOG_N, true, W::WAVE>(s2, lane, nullptr, lds, true, k);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        out[e] = (u64)round_small(s0[e].x) + ((u64)round_small(s1[e].x) << 22) + ((u64)round_small(s2[e].x) << 43);
+        out[E + e] = (u64)round_small(s0[e].y) + ((u64)round_small(s1[e].y) << 22) + ((u64)round_small(s2[e].y) << 43);
+    }
+}
+
+// r = 0xffffffff: plain external product; else one CMUX step (r in [1, 2N)).  lds64: the team's image, then its digit area
+template <class W>
+__device__ __forceinline__ void teamx3_cmux(u64 (&ca)[2 * W::E], u64 (&cb)[2 * W::E], unsigned r, const double2 *__restrict__ rows, const TDecomp &P,
+                                            const ArithC64::K &k, int lane, u64 *lds64) {
+    constexpr int E = W::E;
+    const bool plain = r == 0xffffffffu;
+    if (r == 0) return;  // team-uniform
+    unsigned *dig = reinterpret_cast<unsigned *>(lds64 + TorusX3<W>::IMG_WORDS);
+    {
+        u64 da[2 * E], db[2 * E];
+#pragma unroll
+        for (int e = 0; e < 2 * E; ++e) { da[e] = ca[e]; db[e] = cb[e]; }
+        if (!plain) {
+            pairs_rotate<W>(da, r, lane, lds64);
+            pairs_rotate<W>(db, r, lane, lds64);
+#pragma unroll
+            for (int e = 0; e < 2 * E; ++e) { da[e] -= ca[e]; db[e] -= cb[e]; }
+        }
+        park_digits_x3<W>(da, db, P, lane, dig);
+    }
+    u64 x[2 * E];
+    x3_output<W>(dig, rows, 2 * P.d, 0, lane, reinterpret_cast<double2 *>(lds64), k, x);
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) ca[e] = plain ? x[e] : ca[e] + x[e];
+    x3_output<W>(dig, rows, 2 * P.d, 1, lane, reinterpret_cast<double2 *>(lds64), k, x);
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) cb[e] = plain ? x[e] : cb[e] + x[e];
+}
+
+template <class W>
+__device__ __forceinline__ const double2 *stage_twiddles_x3(const double2 *__restrict__ tw, unsigned char *smem_raw, int limbs) {
+    double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<u64 *>(smem_raw) + TorusX3<W>::lds_words(limbs) * W::TEAMS);
+    for (int i = threadIdx.x; i < TorusX3<W>::N; i += W::THREADS) dst[i] = tw[i];
+    __syncthreads();
+    return dst;
+}
+
+template <class W, int MIN_WAVES>
+__global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusx3_cmux_kernel(u64 *__restrict__ acc_a, u64 *__restrict__ acc_b, unsigned batch,
+                                                                             const double2 *__restrict__ rows, TDecomp P, const u64 *__restrict__ rot,
+                                                                             size_t rot_stride, const double2 *__restrict__ tw) {
+    constexpr int E = W::E, N = 2 * W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    const ArithC64::K k = ArithC64::make(stage_twiddles_x3<W>(tw, smem_raw, 2 * P.d), W::LOG_N);
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusX3<W>::lds_words(2 * P.d);
+    u64 *ga = acc_a + size_t(ct) * N, *gb = acc_b + size_t(ct) * N;
+    u64 ca[2 * E], cb[2 * E];
+    pairs_load<W>(ca, ga, lane);
+    pairs_load<W>(cb, gb, lane);
+    teamx3_cmux<W>(ca, cb, rot ? unsigned(rot[size_t(ct) * rot_stride]) & (2 * N - 1) : 0xffffffffu, rows, P, k, lane, lds);
+    pairs_store<W>(ca, ga, lane);
+    pairs_store<W>(cb, gb, lane);
+}
+
+// bootstrapping.rs:84-96 in one launch; rows: [n_lwe][2d][2][3][M] complex
+template <class W, int MIN_WAVES>
+__global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusx3_blind_rotate_kernel(const u64 *__restrict__ v, const u64 *__restrict__ a_tilde,
+                                                                                     const u64 *__restrict__ b_tilde, unsigned n_lwe, unsigned batch,
+                                                                                     const double2 *__restrict__ rows, TDecomp P,
+                                                                                     const double2 *__restrict__ tw, u64 *__restrict__ out_a,
+                                                                                     u64 *__restrict__ out_b) {
+    constexpr int E = W::E, N = 2 * W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const unsigned ct = blockIdx.x * W::TEAMS + team;
+    const ArithC64::K k = ArithC64::make(stage_twiddles_x3<W>(tw, smem_raw, 2 * P.d), W::LOG_N);
+    if (ct >= batch) return;
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw) + team * TorusX3<W>::lds_words(2 * P.d);
+    u64 ca[2 * E], cb[2 * E];
+    pairs_load<W>(cb, v, lane);
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) ca[e] = 0;
+    pairs_rotate<W>(cb, (2 * N - (unsigned(b_tilde[ct]) & (2 * N - 1))) & (2 * N - 1), lane, lds);
+    const size_t per = size_t(2 * P.d) * 6 * W::N;
+    const u64 *a = a_tilde + size_t(ct) * n_lwe;
+#pragma unroll 1
+    for (unsigned i = 0; i < n_lwe; ++i) {
+        const unsigned r = __builtin_amdgcn_readfirstlane(unsigned(a[i]) & (2 * N - 1));
+        teamx3_cmux<W>(ca, cb, r, rows + i * per, P, k, lane, lds);
+    }
+    pairs_store<W>(ca, out_a + size_t(ct) * N, lane);
+    pairs_store<W>(cb, out_b + size_t(ct) * N, lane);
+}
+
+// key preparation for the three-piece form: job = (row, a | b, piece) -> [row][a | b][piece][M] complex evaluations
+template <class W>
+__global__ __launch_bounds__(W::THREADS) void torusx3_key_prepare_kernel(const u64 *__restrict__ rows_a, const u64 *__restrict__ rows_b, size_t n_rows,
+                                                                         const double2 *__restrict__ tw, double2 *__restrict__ out) {
+    constexpr int E = W::E, M = W::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = W::lane(), team = W::team();
+    const size_t job = size_t(blockIdx.x) * W::TEAMS + team;
+    const ArithC64::K k = ArithC64::make(stage_twiddles<W>(tw, smem_raw), W::LOG_N);
+    if (job >= 6 * n_rows) return;
+    double2 *lds = reinterpret_cast<double2 *>(reinterpret_cast<u64 *>(smem_raw) + team * TorusF<W>::LDS_WORDS);
+    const size_t row = job / 6;
+    const int o = int((job / 3) & 1), piece = int(job % 3);
+    const u64 *src = (o ? rows_b : rows_a) + row * (2 * M);
+    double2 x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = coef_index<W>(lane, e);
+        double plo[3], phi[3];
+        key_pieces(src[c], plo);
+        key_pieces(src[c + M], phi);
+        x[e].x = piece == 0 ? plo[0] : (piece == 1 ? plo[1] : plo[2]);
+        x[e].y = piece == 0 ? phi[0] : (piece == 1 ? phi[1] : phi[2]);
+    }
+    fwd_run<ArithC64, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+    double2 *dst = out + job * M;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[e * W::TEAM + lane] = x[e];
+}
+
 // key preparation: signed torus rows [rows][N] (a | b) -> complex evaluations [row][a | b][M] in the KeyRowF layout
 // (c64.rs:19-29: key words converted with `to_i64() as f64`, round to nearest)
 template <class W>

@@ -274,11 +274,12 @@ def test_external_product_at_the_path_boundary(fhe, torch_cuda, log_b, d):
 
 # ---- cfg5's ring, N = 2^10: every instantiation bench.py times, against the exact oracle's C restatement (oracle/ref_ring.c) ----
 
-@pytest.mark.parametrize("log_b,d,path", [(7, 3, "three 30-bit primes (the cfg5 gadget)"), (10, 2, "three 30-bit primes"),
+@pytest.mark.parametrize("log_b,d,path", [(7, 3, "three key pieces through f64 transforms (the cfg5 gadget)"), (10, 2, "three 30-bit primes"),
                                            (23, 1, "two 60-bit primes"), (16, 2, "two 60-bit primes")])
 def test_tggsw_external_product_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, path):
-    """scheme/tfhe/src/tggsw.rs:100-112 at N = 1024 on BOTH prime paths (fhe_tggsw_prepare picks the path from the bound
-    2d N 2^(62 + log_b): (7,3) -> 2^82, (10,2) -> 2^85: 30-bit primes; (23,1) -> 2^97, (16,2) -> 2^91: 60-bit primes),
+    """scheme/tfhe/src/tggsw.rs:100-112 at N = 1024 on EVERY exact path (fhe_tggsw_prepare picks: 2d N 2^log_b <= 2^23 and base <= 2^7:
+    three key pieces through f64 transforms, (7,3); else from the bound 2d N 2^(62 + log_b): (10,2) -> 2^85: three 30-bit primes;
+    (23,1) -> 2^97, (16,2) -> 2^91: two 60-bit primes),
     two key entries, a ragged batch with extreme torus values; bit-equal to the exact product"""
     n, batch, count = 1024, 5, 2
     rng = np.random.Generator(np.random.PCG64(1000 + log_b))
@@ -298,6 +299,59 @@ def test_tggsw_external_product_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d,
         for i in range(batch):
             ea, eb = cref.tggsw_external_product(log_b, d, ra[idx], rb[idx], ca[i], cb[i])
             assert np.array_equal(ha[i], ea) and np.array_equal(hb[i], eb), (path, idx, i)
+
+
+@pytest.mark.parametrize("log_n,log_b,d", [(10, 7, 3), (10, 7, 4), (10, 6, 4), (9, 7, 4), (8, 7, 4), (10, 4, 7), (8, 2, 8)])
+def test_exact_f64_path_equals_the_integer_paths_on_worst_case_operands(fhe, cref, torch_cuda, log_n, log_b, d):
+    """The three-piece f64 path (csrc/torusf_kernels.hpp TorusX3: key words cut into signed pieces of 22 / 21 / 21 bits, half-size complex
+    transforms, every product rounded to the integer it is) must be EXACT, not close: here against the oracle and against the three-prime
+    integer path (lab switch NO_F64_EXACT) on the operands that make the rounding error largest -- every digit at +-2^(log_b - 1) and every
+    key piece at its extreme (key words 0x7fff..., 0x8000..., and the word whose three pieces are all at their negative end), constant and
+    alternating in sign, besides uniform ones; the largest gadget the path takes ((10,7,4): 2d N 2^log_b = 2^20 of the 2^23 the error bound
+    allows), cfg5's (10,7,3), long ones ((10,4,7): 14 limbs, (8,2,8): 16 limbs); external product, CMUX and a short blind rotation."""
+    n, batch = 1 << log_n, 6
+    rng = np.random.Generator(np.random.PCG64(7000 + log_n * 10 + d))
+    r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)  # noqa: E731
+    n_lwe = 4
+    ra, rb = r64(n_lwe, 2 * d, n), r64(n_lwe, 2 * d, n)
+    low = ((-(1 << 21)) + ((-(1 << 20)) << 22) + ((-(1 << 20)) << 43)) % (1 << 64)       # all three pieces at their negative end
+    ra[0, :, :] = np.uint64((1 << 63) - 1)
+    rb[0, :, :] = np.uint64(1 << 63)
+    ra[1, :, :] = np.uint64(low)
+    rb[1, :, 0::2] = np.uint64((1 << 63) - 1)
+    rb[1, :, 1::2] = np.uint64(1 << 63)
+    half = 1 << (log_b - 1)
+    neg = (-sum(half << (64 - log_b * (j + 1)) for j in range(d) if 64 - log_b * (j + 1) >= 0)) % (1 << 64)   # every digit -2^(log_b-1)
+    pos = (-neg) % (1 << 64)
+    ca, cb = r64(batch, n), r64(batch, n)
+    ca[0, :], cb[0, :] = np.uint64(neg), np.uint64(pos)
+    ca[1, 0::2], ca[1, 1::2], cb[1, :] = np.uint64(neg), np.uint64(pos), np.uint64(neg)
+    t = fhe.TorusContext()
+    res = []
+    for off in (0, 1):  # the f64 path | the integer path
+        fhe.set_option("NO_F64_EXACT", off)
+        try:
+            key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n)
+        finally:
+            fhe.set_option("NO_F64_EXACT", 0)
+        outs = []
+        for idx in range(2):
+            a, b = dev(torch_cuda, ca), dev(torch_cuda, cb)
+            key.external_product_(idx, a, b)
+            outs += [a, b]
+        outs += list(key.cmux(1, dev(torch_cuda, ca), dev(torch_cuda, cb), dev(torch_cuda, cb), dev(torch_cuda, ca)))
+        a_t = rng.integers(1, 2 * n, size=(batch, n_lwe), dtype=np.uint64) if off == 0 else a_t  # noqa: F821
+        b_t = rng.integers(0, 2 * n, size=batch, dtype=np.uint64) if off == 0 else b_t          # noqa: F821
+        outs += list(key.blind_rotate(dev(torch_cuda, a_t), dev(torch_cuda, b_t), dev(torch_cuda, ca[0])))
+        res.append(outs)
+    for x, y in zip(*res):
+        assert torch_cuda.equal(x, y)
+    for idx in range(2):
+        for i in range(batch):
+            ea, eb = cref.tggsw_external_product(log_b, d, ra[idx], rb[idx], ca[i], cb[i])
+            assert np.array_equal(host(res[0][2 * idx])[i], ea) and np.array_equal(host(res[0][2 * idx + 1])[i], eb), (idx, i)
+    ea, eb = cref.tfhe_blind_rotate(log_b, d, ra, rb, ca[0], a_t, b_t, threads=8)
+    assert np.array_equal(host(res[0][6]).reshape(batch, n), ea) and np.array_equal(host(res[0][7]).reshape(batch, n), eb)
 
 
 @pytest.mark.parametrize("log_b,d,n_lwe,batch", [(7, 3, 10, 7), (23, 1, 8, 7), (7, 3, 4, 1100), (23, 1, 3, 600)])

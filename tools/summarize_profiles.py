@@ -125,7 +125,7 @@ if fwd:
     print("wrote profiles/pmc_summary.json", fwd["bytes_per_launch"], inv["bytes_per_launch"] if inv else None)
 
 # ---- the secondary workloads' kernels (bench.py blocks ntt_mul / fhew / ckks / tfhe): HBM bytes per launch, wave-cycle split ----
-SECONDARY = ("blind_rotate_kernel", "torus30_blind_rotate_kernel", "torusf_blind_rotate_kernel", "external_product_kernel", "gadget_product_kernel", "ntt14w_fwd_kernel", "ntt14w_inv_kernel",
+SECONDARY = ("blind_rotate_kernel", "torus30_blind_rotate_kernel", "torusf_blind_rotate_kernel", "torusx3_blind_rotate_kernel", "external_product_kernel", "gadget_product_kernel", "ntt14w_fwd_kernel", "ntt14w_inv_kernel",
              "ntt14w_mul_kernel", "ntt_big_fwd_pass", "ntt_big_inv_pass", "rns_rescale", "rns_extend", "tlwe_key_switch", "lwe_key_switch")
 sec = {}
 for k, e in summary.items():
