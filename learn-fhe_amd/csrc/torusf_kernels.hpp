@@ -318,7 +318,9 @@ struct TorusX3 {
     static constexpr int M = W::N, N = 2 * W::N, E = W::E;
     static constexpr int IMG_WORDS = 2 * W::PN;
     static constexpr int DIG_WORDS_PER_LIMB = W::TEAM;          // 2 dwords per lane and limb (E <= 4 digits each) = TEAM 8-byte words
-    static __host__ __device__ constexpr int lds_words(int limbs) { return IMG_WORDS + limbs * DIG_WORDS_PER_LIMB; }  // per team
+    // per team: exchange / rotation image | one half of the accumulator (N words, lane-private slots: whichever half the running output
+    // pass does not need) | the digits
+    static __host__ __device__ constexpr int lds_words(int limbs) { return IMG_WORDS + N + limbs * DIG_WORDS_PER_LIMB; }
     static __host__ __device__ constexpr size_t lds_bytes(int limbs) { return size_t(lds_words(limbs) * W::TEAMS + 2 * N) * 8; }  // + the twiddle tree
     static_assert(W::E <= 4, "digits of a lane's E slots are packed into one dword");
 };
@@ -388,13 +390,20 @@ __device__ __forceinline__ void x3_output(const unsigned *dig, const double2 *__
             x[e].x = (double)((int)(wl << (24 - 8 * e)) >> 24);
             x[e].y = (double)((int)(wh << (24 - 8 * e)) >> 24);
         }
-        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+        // the limb's key rows are requested BEFORE its transform and consumed after it: the fetch (L2 / Infinity Cache) flies under the
+        // butterflies instead of stalling the wave in front of the multiply-accumulates
+        double2 k0[E], k1[E], k2[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int slot = e * W::TEAM + lane;
-            cmac(s0[e], x[e], row[slot]);
-            cmac(s1[e], x[e], row[M + slot]);
-            cmac(s2[e], x[e], row[2 * M + slot]);
+            k0[e] = row[slot]; k1[e] = row[M + slot]; k2[e] = row[2 * M + slot];
+        }
+        fwd_run<A, typename W::C, W::LOG_N, W::LOG_E, 0, true, W::WAVE>(x, lane, nullptr, lds, true, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            cmac(s0[e], x[e], k0[e]);
+            cmac(s1[e], x[e], k1[e]);
+            cmac(s2[e], x[e], k2[e]);
         }
         row += 6 * M;
     }
@@ -415,7 +424,8 @@ __device__ __forceinline__ void teamx3_cmux(u64 (&ca)[2 * W::E], u64 (&cb)[2 * W
     constexpr int E = W::E;
     const bool plain = r == 0xffffffffu;
     if (r == 0) return;  // team-uniform
-    unsigned *dig = reinterpret_cast<unsigned *>(lds64 + TorusX3<W>::IMG_WORDS);
+    u64 *park = lds64 + TorusX3<W>::IMG_WORDS;
+    unsigned *dig = reinterpret_cast<unsigned *>(park + TorusX3<W>::N);
     {
         u64 da[2 * E], db[2 * E];
 #pragma unroll
@@ -428,13 +438,24 @@ __device__ __forceinline__ void teamx3_cmux(u64 (&ca)[2 * W::E], u64 (&cb)[2 * W
         }
         park_digits_x3<W>(da, db, P, lane, dig);
     }
+    // each output pass runs with only the half it adds to in registers: the other half waits in the team's LDS slots (the prefetched
+    // key rows need the room)
     u64 x[2 * E];
+#pragma unroll
+    for (int e = 0; e < 2 * E; ++e) park[e * W::TEAM + lane] = cb[e];
     x3_output<W>(dig, rows, 2 * P.d, 0, lane, reinterpret_cast<double2 *>(lds64), k, x);
 #pragma unroll
-    for (int e = 0; e < 2 * E; ++e) ca[e] = plain ? x[e] : ca[e] + x[e];
+    for (int e = 0; e < 2 * E; ++e) {
+        ca[e] = plain ? x[e] : ca[e] + x[e];
+        cb[e] = park[e * W::TEAM + lane];
+        park[e * W::TEAM + lane] = ca[e];
+    }
     x3_output<W>(dig, rows, 2 * P.d, 1, lane, reinterpret_cast<double2 *>(lds64), k, x);
 #pragma unroll
-    for (int e = 0; e < 2 * E; ++e) cb[e] = plain ? x[e] : cb[e] + x[e];
+    for (int e = 0; e < 2 * E; ++e) {
+        cb[e] = plain ? x[e] : cb[e] + x[e];
+        ca[e] = park[e * W::TEAM + lane];
+    }
 }
 
 template <class W>
