@@ -285,7 +285,7 @@ int fhe_torus_mul(const fhe_torus_ctx *t, uint64_t *a, const uint64_t *b, int lo
                   void *stream);
 /* `count` TGGSW ciphertexts (scheme/tfhe/src/tggsw.rs:44-88): rows_a / rows_b [count][2d][n].  n = 256 .. 2048.  The exact products run on
  * one of three forms chosen from the gadget: key words cut into three signed pieces through f64 transforms whose rounded results are exact
- * (2d n 2^log_b <= 2^23, base <= 2^7: BASELINE config 5), three 30-bit NTT primes (2d n 2^(62 + log_b) < 2^88), two 60-bit primes
+ * (2d n 2^log_b <= 2^21, base <= 2^7: BASELINE config 5), three 30-bit NTT primes (2d n 2^(62 + log_b) < 2^88), two 60-bit primes
  * (< 2^118; beyond that FHE_ERR_UNSUPPORTED).  All three give the same bits. */
 int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *rows_a, const uint64_t *rows_b, size_t n, size_t count,
                       fhe_mem mem, fhe_tggsw_key **out);

@@ -314,10 +314,10 @@ int fhe_tggsw_prepare(const fhe_torus_ctx *t, int log_b, int d, const uint64_t *
     const int bound_bits = ilog2((size_t)2 * d) + 1 + log_n + 62 + log_b;
     if (bound_bits > 118) return FHE_ERR_UNSUPPORTED;              // two 60-bit primes: P / 2 ~ 2^118.9
     const bool use30 = bound_bits <= 88 && log_b <= 28;            // three 30-bit primes: P / 2 ~ 2^88.9 (torus30_kernels.hpp)
-    // exact through f64 transforms of three key pieces (torusf_kernels.hpp: TorusX3): 2d N 2^log_b <= 2^23 keeps the rounding error a factor
-    // 30 inside 1/2; digits must be bytes (log_b <= 7) and their state a dword (log_b d <= 31), at most 16 limbs (the digit area in LDS);
+    // exact through f64 transforms of three key pieces (torusf_kernels.hpp: TorusX3): 2d N 2^log_b <= 2^21 keeps the rounding error a factor
+    // 12 inside 1/2; digits must be bytes (log_b <= 7) and their state a dword (log_b d <= 31), at most 16 limbs (the digit area in LDS);
     // N <= 1024 (four slots per lane at most)
-    const bool usex3 = (size_t(2 * d) << (log_n + log_b)) <= (size_t(1) << 23) && log_b <= 7 && log_b * d <= 31 && 2 * d <= 16 && log_n <= 10 &&
+    const bool usex3 = (size_t(2 * d) << (log_n + log_b)) <= (size_t(1) << 21) && log_b <= 7 && log_b * d <= 31 && 2 * d <= 16 && log_n <= 10 &&
                        fhe::opt(fhe::OPT_NO_F64_EXACT) == 0;
     DeviceGuard guard(t->device);
     if (!guard.ok) return FHE_ERR_HIP;

@@ -303,10 +303,10 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
 // (|digit| <= 2^(log_b - 1)) with ONE piece has coefficients below N 2^(log_b + 20): integers that an f64 transform of this size
 // reproduces with an error far below 1/2, so rounding recovers them EXACTLY, and the three rounded products recombine to the
 // exact product mod 2^64 with shifts and wrapping adds.  Error bound (Percival 2003 for FFT convolutions: |err| <= ||x||_2 ||y||_2
-// ((1 + eps)^(3 n) (1 + eps sqrt 5)^(3 n + 1) (1 + beta)^(3 n) - 1), n = log2 of the transform size, beta ~ eps the twiddle error:
-// <= 130 eps for n <= 10): ||digits||_2 <= sqrt(N) 2^(log_b - 1), ||piece||_2 <= sqrt(N) 2^21, 2d products summed:
-// err <= 2d N 2^(log_b + 20) 130 2^-53.  The host takes this path only while 2d N 2^log_b <= 2^23 (err <= 0.016 at the limit: a factor
-// 30 inside 1/2; cfg5: 2d N 2^log_b = 2^19.6, err <= 1.5e-3): the result is the exact oracle's, bit for bit, and the whole-gate and
+// ((1 + eps)^(3 n) (1 + eps sqrt 5)^(3 n + 1) (1 + beta)^(3 n) - 1), eps = 2^-53, n = log2 of the transform size, beta <= 2 eps the
+// twiddle error: <= 160 eps for n <= 10): ||digits||_2 <= sqrt(N) 2^(log_b - 1), ||piece||_2 <= sqrt(N) 2^21, 2d products summed:
+// err <= 2d N 2^(log_b + 20) 160 2^-53.  The host takes this path only while 2d N 2^log_b <= 2^21 (err <= 0.04 at the limit: a factor
+// 12 inside 1/2; cfg5: 2d N 2^log_b = 2^19.6, err <= 0.015): the result is the exact oracle's, bit for bit, and the whole-gate and
 // extreme-operand tests of tests/test_torus_gpu.py hold it to that.  One CMUX = the digits once (bytes, parked in LDS), then per
 // output (a, b): 2d forward transforms, 3 x 2d multiply-accumulates per slot, three inverse transforms, cheap roundings (|value| <
 // 2^40: the magic-constant trick) and the recombination: 12 + 6 half-size complex transforms where the three-prime path runs 24

@@ -277,7 +277,7 @@ def test_external_product_at_the_path_boundary(fhe, torch_cuda, log_b, d):
 @pytest.mark.parametrize("log_b,d,path", [(7, 3, "three key pieces through f64 transforms (the cfg5 gadget)"), (10, 2, "three 30-bit primes"),
                                            (23, 1, "two 60-bit primes"), (16, 2, "two 60-bit primes")])
 def test_tggsw_external_product_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, path):
-    """scheme/tfhe/src/tggsw.rs:100-112 at N = 1024 on EVERY exact path (fhe_tggsw_prepare picks: 2d N 2^log_b <= 2^23 and base <= 2^7:
+    """scheme/tfhe/src/tggsw.rs:100-112 at N = 1024 on EVERY exact path (fhe_tggsw_prepare picks: 2d N 2^log_b <= 2^21 and base <= 2^7:
     three key pieces through f64 transforms, (7,3); else from the bound 2d N 2^(62 + log_b): (10,2) -> 2^85: three 30-bit primes;
     (23,1) -> 2^97, (16,2) -> 2^91: two 60-bit primes),
     two key entries, a ragged batch with extreme torus values; bit-equal to the exact product"""
@@ -307,8 +307,8 @@ def test_exact_f64_path_equals_the_integer_paths_on_worst_case_operands(fhe, cre
     transforms, every product rounded to the integer it is) must be EXACT, not close: here against the oracle and against the three-prime
     integer path (lab switch NO_F64_EXACT) on the operands that make the rounding error largest -- every digit at +-2^(log_b - 1) and every
     key piece at its extreme (key words 0x7fff..., 0x8000..., and the word whose three pieces are all at their negative end), constant and
-    alternating in sign, besides uniform ones; the largest gadget the path takes ((10,7,4): 2d N 2^log_b = 2^20 of the 2^23 the error bound
-    allows), cfg5's (10,7,3), long ones ((10,4,7): 14 limbs, (8,2,8): 16 limbs); external product, CMUX and a short blind rotation."""
+    alternating in sign, besides uniform ones; the largest gadget the path takes ((10,7,4): 2d N 2^log_b = 2^20 of the 2^21 the host
+    admits), cfg5's (10,7,3), long ones ((10,4,7): 14 limbs, (8,2,8): 16 limbs); external product, CMUX and a short blind rotation."""
     n, batch = 1 << log_n, 6
     rng = np.random.Generator(np.random.PCG64(7000 + log_n * 10 + d))
     r64 = lambda *s: rng.integers(0, 1 << 63, size=s, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=s, dtype=np.uint64)  # noqa: E731
