@@ -306,7 +306,8 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
 // ((1 + eps)^(3 n) (1 + eps sqrt 5)^(3 n + 1) (1 + beta)^(3 n) - 1), eps = 2^-53, n = log2 of the transform size, beta <= 2 eps the
 // twiddle error: <= 160 eps for n <= 10): ||digits||_2 <= sqrt(N) 2^(log_b - 1), ||piece||_2 <= sqrt(N) 2^21, 2d products summed:
 // err <= 2d N 2^(log_b + 20) 160 2^-53.  The host takes this path only while 2d N 2^log_b <= 2^21 (err <= 0.04 at the limit: a factor
-// 12 inside 1/2; cfg5: 2d N 2^log_b = 2^19.6, err <= 0.015): the result is the exact oracle's, bit for bit, and the whole-gate and
+// 12 inside 1/2; cfg5: 2d N 2^log_b = 2^19.6, err <= 0.015; the six-FMA butterfly forms its difference as 2X - (X + wY), at most twice a
+// plain butterfly's rounding error: inside those factors): the result is the exact oracle's, bit for bit, and the whole-gate and
 // extreme-operand tests of tests/test_torus_gpu.py hold it to that.  One CMUX = the digits once (bytes, parked in LDS), then per
 // output (a, b): 2d forward transforms, 3 x 2d multiply-accumulates per slot, three inverse transforms, cheap roundings (|value| <
 // 2^40: the magic-constant trick) and the recombination: 12 + 6 half-size complex transforms where the three-prime path runs 24

@@ -90,6 +90,38 @@ def test_fft64_small_operands_are_exact(fhe, cref, torch_cuda, log_n):
     assert np.array_equal(host(oa).reshape(batch, n), ea) and np.array_equal(host(ob).reshape(batch, n), eb)
 
 
+@pytest.mark.parametrize("log_n,log_b,d", [(10, 7, 3), (10, 7, 4), (9, 7, 4)])
+def test_f64_transforms_keep_a_margin_beyond_the_exact_paths_operands(fhe, cref, torch_cuda, log_n, log_b, d):
+    """The exact mode's three-piece path (csrc/torusf_kernels.hpp TorusX3) relies on these transforms reproducing integer products with an
+    error below 1/2 for key pieces up to 2^21 in magnitude (bound in DESIGN.md section 9: <= 0.04).  The fft64 mode runs the SAME butterflies
+    on whatever key words it is given, so it measures the margin: with every digit at +-2^(log_b - 1) and key words at +-2^21 x 2^s, random
+    and alternating signs, its output must still be bit-equal to the exact product for s = 0 (the pieces' size) and for s = 3 and 5 (8 and
+    32 times larger: the bound would be 0.3 and 1.3) -- the error in practice sits far inside the worst-case bound."""
+    n, batch = 1 << log_n, 4
+    rng = np.random.Generator(np.random.PCG64(900 + log_n + d))
+    half = 1 << (log_b - 1)
+    neg = (-sum(half << (64 - log_b * (j + 1)) for j in range(d))) % (1 << 64)
+    pos = (-neg) % (1 << 64)
+    ca, cb = np.empty((batch, n), dtype=np.uint64), np.empty((batch, n), dtype=np.uint64)
+    ca[0, :], cb[0, :] = np.uint64(neg), np.uint64(pos)
+    ca[1, 0::2], ca[1, 1::2], cb[1, :] = np.uint64(neg), np.uint64(pos), np.uint64(neg)
+    sign = rng.integers(0, 2, size=(2, 2, n), dtype=np.uint64)
+    ca[2:], cb[2:] = np.where(sign[0] == 1, np.uint64(neg), np.uint64(pos)), np.where(sign[1] == 1, np.uint64(neg), np.uint64(pos))
+    t = fhe.TorusContext()
+    for s_ in (0, 3, 5):
+        mag = (1 << (21 + s_)) - 1
+        ra = np.where(rng.integers(0, 2, size=(1, 2 * d, n)) == 1, mag, -mag).astype(np.int64).view(np.uint64)
+        rb = np.full((1, 2 * d, n), mag, dtype=np.int64)
+        rb[:, :, 1::2] = -mag
+        rb = rb.view(np.uint64)
+        key = fhe.TggswKey(t, log_b, d, dev(torch_cuda, ra), dev(torch_cuda, rb), n, fft64=True)
+        xa, xb = dev(torch_cuda, ca), dev(torch_cuda, cb)
+        key.external_product_(0, xa, xb)
+        for i in range(batch):
+            ea, eb = cref.tggsw_external_product(log_b, d, ra[0], rb[0], ca[i], cb[i])
+            assert np.array_equal(host(xa)[i], ea) and np.array_equal(host(xb)[i], eb), (s_, i)
+
+
 @pytest.mark.parametrize("n,n_lwe,log_p,log_b,d,sd_lwe,sd_glwe", [(2048, 1024, 4, 23, 1, 1.339775301998614e-7, 2.845267479601915e-15),
                                                                    (1024, 630, 3, 7, 3, 2.0 ** -20, 2.0 ** -25)])
 def test_fft64_gate_bootstrap_decode_level(fhe, torch_cuda, n, n_lwe, log_p, log_b, d, sd_lwe, sd_glwe):
