@@ -354,6 +354,30 @@ def test_exact_f64_path_equals_the_integer_paths_on_worst_case_operands(fhe, cre
     assert np.array_equal(host(res[0][6]).reshape(batch, n), ea) and np.array_equal(host(res[0][7]).reshape(batch, n), eb)
 
 
+def test_exact_f64_path_whole_cfg5_blind_rotations_equal_the_integer_path(fhe, torch_cuda):
+    """BASELINE config 5 at full length on both exact paths: 630 CMUXes x 512 ciphertexts with uniform 64-bit key words -- 660 million
+    coefficients, each rounded three times on the f64 path; one rounding the wrong way anywhere would re-randomise everything after it.
+    Every accumulator of the three-piece f64 path is bit-identical to the three-prime integer path's (which the oracle tests pin)."""
+    n, n_lwe, log_b, d, batch = 1024, 630, 7, 3, 512
+    gen = torch_cuda.Generator(device="cuda")
+    gen.manual_seed(55)
+    rnd = lambda *shape: torch_cuda.randint(-(1 << 63), (1 << 63) - 1, shape, dtype=torch_cuda.int64, device="cuda", generator=gen)  # noqa: E731
+    ra, rb, v = rnd(n_lwe, 2 * d, n), rnd(n_lwe, 2 * d, n), rnd(n)
+    a_t = torch_cuda.randint(0, 2 * n, (batch, n_lwe), dtype=torch_cuda.int64, device="cuda", generator=gen)
+    b_t = torch_cuda.randint(0, 2 * n, (batch,), dtype=torch_cuda.int64, device="cuda", generator=gen)
+    t = fhe.TorusContext()
+    outs = []
+    for off in (0, 1):
+        fhe.set_option("NO_F64_EXACT", off)
+        try:
+            key = fhe.TggswKey(t, log_b, d, ra, rb, n)
+        finally:
+            fhe.set_option("NO_F64_EXACT", 0)
+        outs.append(key.blind_rotate(a_t, b_t, v))
+        del key
+    assert torch_cuda.equal(outs[0][0], outs[1][0]) and torch_cuda.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("log_b,d,n_lwe,batch", [(7, 3, 10, 7), (23, 1, 8, 7), (7, 3, 4, 1100), (23, 1, 3, 600)])
 def test_blind_rotate_n1024_vs_oracle(fhe, cref, torch_cuda, log_b, d, n_lwe, batch):
     """scheme/tfhe/src/bootstrapping.rs:84-104 at N = 1024 (cfg5's ring): mod switch, the whole CMUX chain, sample extract and the
