@@ -314,6 +314,9 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
 // full-size 30-bit ones.  Measured and dropped: both outputs in ONE pass over the limbs (six sums per slot, the accumulator parked in
 // LDS, twiddles from HBM for want of LDS: 6 + 6 transforms, 192 registers) -- 32.2 k gates/s at cfg5 against 34.1 k for the two passes
 // (25.4 k against 31.2 k at batch 4096): six key streams per slot consumed the moment they are requested cost more than six transforms.
+// Also measured and dropped (on the prefetching form, 46.3 k): every limb transformed ONCE and kept in registers (2d x E complex values, 238
+// registers, no spill; 2d + 6 transforms), the two output passes then loads and multiply-accumulates only -- 34.6 k: with no transform to fly
+// under, the key rows are waited for in full.
 template <class W>
 struct TorusX3 {
     static constexpr int M = W::N, N = 2 * W::N, E = W::E;
