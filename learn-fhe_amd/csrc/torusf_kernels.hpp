@@ -316,7 +316,8 @@ __global__ __launch_bounds__(W::THREADS, MIN_WAVES) void torusf_blind_rotate_ker
 // (25.4 k against 31.2 k at batch 4096): six key streams per slot consumed the moment they are requested cost more than six transforms.
 // Also measured and dropped (on the prefetching form, 46.3 k): every limb transformed ONCE and kept in registers (2d x E complex values, 238
 // registers, no spill; 2d + 6 transforms), the two output passes then loads and multiply-accumulates only -- 34.6 k: with no transform to fly
-// under, the key rows are waited for in full.
+// under, the key rows are waited for in full; and the hybrid (the a output as here, under the transforms, their evaluations kept for a b output of
+// loads and products only: 256 registers, 14 spilled): 47.6 k at batch 1024 but 38.8 k at 4096 and 13.3 k at 256 (46.1 k / 18.8 k here).
 template <class W>
 struct TorusX3 {
     static constexpr int M = W::N, N = 2 * W::N, E = W::E;
