@@ -533,3 +533,20 @@ def test_packed_digit_blind_rotation_equals_the_unpacked_one(fhe, torch_cuda, lo
     if (log_n, log_b, d) == (10, 7, 3):
         ea, eb = cref.tfhe_blind_rotate(log_b, d, ra, rb, v, a_t, b_t, threads=8)
         assert np.array_equal(host(outs[0][0]).reshape(batch, n), ea) and np.array_equal(host(outs[0][1]).reshape(batch, n), eb)
+
+
+def test_c_program_tfhe_gate(tmp_path, fhe):
+    """examples/tfhe_gate_demo.c: row T through the boundary from plain C (no Python, no torch in that process): TGGSW external product
+    against a schoolbook computed in the C program -- exact mode bit for bit, fft64 mode within the reference's bound -- the single-call
+    gate on host buffers, status codes."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.dirname(fhe.lib_path())
+    exe = tmp_path / "tfhe_gate_demo"
+    cmd = ["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "tfhe_gate_demo.c"), "-o", str(exe),
+           "-L", lib_dir, "-lfhe_ring", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "tfhe_gate_demo ok" in r.stdout, r.stdout + r.stderr
