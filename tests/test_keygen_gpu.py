@@ -294,3 +294,26 @@ def test_rng_domain_separation_and_stream_ids(fhe, torch_cuda):
     other = fhe.Rng(key=bytes(range(31)) + b"\x9f")
     assert not set(L(host(fhe.sample_torus(other, 7, like, (n,))))) & words
     assert not np.array_equal(host(fhe.sample_torus(fhe.Rng(), 0, like, (n,))), host(fhe.sample_torus(fhe.Rng(), 0, like, (n,))))
+
+
+def test_reference_tlwe_tests_decode_level(fhe, torch_cuda):
+    """The reference's own TLWE tests at ITS parameters on device-made material: scheme/tfhe/src/tlwe.rs:162-174 `encrypt_decrypt`
+    ((log_p, padding, n, std_dev) = (8, 1, 256, 1e-8), every message 0 .. 255) and 176-192 `key_switch` (decomposor base 2^8 x 8: sk0 -> sk1,
+    `ksk_gen(param1, sk1, sk0)`, every message decodes under sk1)."""
+    log_p, padding, n, sd, log_b, d = 8, 1, 256, 1.0e-8, 8, 8
+    p, log_delta = 1 << log_p, 64 - (log_p + padding)
+    like = dev(torch_cuda, U([0]))
+    sk0, sk1 = fhe.sample_binary(950, 0, like, n), fhe.sample_binary(950, 1, like, n)
+    s0, s1 = host(sk0).astype(np.uint64), host(sk1).astype(np.uint64)
+    msgs = np.arange(p, dtype=np.uint64)
+    ca, cb = fhe.tlwe_sk_encrypt(sk0, dev(torch_cuda, msgs << np.uint64(log_delta)), n, p, sd, 951, 0)
+
+    def decode(a, b, s):  # tlwe.rs:134-142: mu* = b - <a, s>, rounded at log_delta, then `decode`
+        ph = b - (a * s[None, :]).sum(axis=1, dtype=np.uint64)
+        return ((ph + np.uint64(1 << (log_delta - 1))) >> np.uint64(log_delta)) % np.uint64(p)
+
+    assert np.array_equal(decode(host(ca), host(cb), s0), msgs)
+    ksa, ksb = fhe.tlwe_ksk_gen(log_b, d, sk1, sk0, sd, 952, 0)      # rows encrypt -sk0_i 2^(8 j) under sk1 (tlwe.rs:100-111)
+    oa, ob = fhe.tlwe_key_switch(log_b, d, ksa, ksb, ca, cb, n, n)
+    assert np.array_equal(decode(host(oa).reshape(p, n), host(ob).reshape(p), s1), msgs)
+    assert not np.array_equal(decode(host(oa).reshape(p, n), host(ob).reshape(p), s0), msgs)   # and no longer under sk0
