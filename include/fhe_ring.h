@@ -250,6 +250,11 @@ int fhe_ckks_shard_finish(const fhe_ckks_shard *shard, const uint64_t *prod_q, c
 /* util/src/ring/rns.rs:99-101 `RnsRq::rescale()` = rescale_k(1) over qs alone: drops the last q-limb (the K == 1 branch of
  * rns.rs:104-111, NOT centred).  in [batch][L][n] -> out [batch][L-1][n]; L >= 2. */
 int fhe_rns_rescale(const fhe_rns_ctx *rns, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem, void *stream);
+/* util/src/ring/rns.rs:254-270 `RnsRq += RnsRq`, `-= RnsRq`, unary `-` in either basis (what `CkksCiphertext` + / - do on both
+ * components: ckks.rs `add_sub`): a <- a + b, a - b, -a over [batch][limbs][n]; extended = 0: qs, 1: qs ++ ps. */
+int fhe_rns_add(const fhe_rns_ctx *rns, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem, void *stream);
+int fhe_rns_sub(const fhe_rns_ctx *rns, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem, void *stream);
+int fhe_rns_neg(const fhe_rns_ctx *rns, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream);
 /* scheme/ckks/src/ckks.rs:127-129 `automorphism(t)` of an RnsRq (util/src/avec.rs:34-50 on every limb): in, out [batch][L][n],
  * in != out.  t is taken mod 2n; CKKS only uses odd t (5^j, -1) and an even t returns FHE_ERR_UNSUPPORTED. */
 int fhe_rns_automorphism(const fhe_rns_ctx *rns, int64_t t, const uint64_t *in, uint64_t *out, size_t n, size_t batch, fhe_mem mem,

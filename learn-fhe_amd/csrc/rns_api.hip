@@ -545,6 +545,36 @@ int fhe_rns_pointwise_mul(const fhe_rns_ctx *r, int extended, uint64_t *a, const
     return ma.sync_out(st);
 }
 
+namespace {
+int rns_addsub(const fhe_rns_ctx *r, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem, void *stream, int op) {
+    if (!r || ((!a || (!b && op != 2)) && n * batch)) return FHE_ERR_INVALID;
+    if (r->device < 0) return FHE_ERR_NO_DEVICE;
+    if (n * batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t limbs = size_t(extended ? r->L + r->K : r->L), count = n * batch * limbs;
+    Mirror ma(a, count, mem, true, st), mb(b, op != 2 ? count : 0, mem, true, st);
+    if (ma.rc | mb.rc) return FHE_ERR_HIP;
+    if (n >> 31) return FHE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fhe::rns_addsub_kernel, PointwiseGrid(n, batch * limbs).g, dim3(256), 0, st, ma.d, (const u64 *)mb.d, (unsigned)n, (unsigned)limbs,
+                       batch * limbs, (const fhe::Barrett *)r->d_barrett, op);
+    HIP_TRY(hipGetLastError());
+    return ma.sync_out(st);
+}
+}  // namespace
+
+// util/src/ring/rns.rs:254-270 `RnsRq += / -= RnsRq`, `-RnsRq` (either basis; CkksCiphertext + / -: ckks.rs add_sub): [batch][limbs][n]
+int fhe_rns_add(const fhe_rns_ctx *r, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return rns_addsub(r, extended, a, b, n, batch, mem, stream, 0);
+}
+int fhe_rns_sub(const fhe_rns_ctx *r, int extended, uint64_t *a, const uint64_t *b, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return rns_addsub(r, extended, a, b, n, batch, mem, stream, 1);
+}
+int fhe_rns_neg(const fhe_rns_ctx *r, int extended, uint64_t *a, size_t n, size_t batch, fhe_mem mem, void *stream) {
+    return rns_addsub(r, extended, a, nullptr, n, batch, mem, stream, 2);
+}
+
 void fhe_ckks_key_destroy(fhe_ckks_key *k) {
     if (!k) return;
     if (k->rns && k->rns->device >= 0) {

@@ -517,6 +517,23 @@ FHE_HEADER_KERNEL void rns_pointwise_kernel(u64 *__restrict__ a, const u64 *__re
     }
 }
 
+// util/src/ring/rns.rs:254-270 `RnsRq` +=, -=, unary - (either basis): a <- a + b (op 0), a - b (op 1), -a (op 2: b unused), limb by limb
+FHE_HEADER_KERNEL void rns_addsub_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, unsigned n, unsigned limbs, size_t polys,
+                                         const Barrett *__restrict__ B, int op) {
+    for (size_t y = blockIdx.y; y < polys; y += gridDim.y) {
+        const u64 q = ldc(&B[unsigned(y % limbs)].q, 0);
+        const size_t base = y * n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const u64 x = a[base + i];
+            u64 r;
+            if (op == 0) r = csub(x + b[base + i], q);
+            else if (op == 1) { const u64 y2 = b[base + i]; r = x >= y2 ? x - y2 : x + q - y2; }
+            else r = x ? q - x : 0;
+            a[base + i] = r;
+        }
+    }
+}
+
 // scheme/ckks/src/ckks.rs:256-260, the tensor of `Ckks::mul` in the evaluation domain, limb by limb:
 // d0 = b0 (.) b1, d1 = b0 (.) a1 + a0 (.) b1, d2 = a0 (.) a1.  e: [4][polys][n] in the order b0, a0, b1, a1 (polys = batch * limbs);
 // d: [3][polys][n].  The products of the reference are coefficient-domain `Rq * Rq` (three transforms each): mathematically the

@@ -423,6 +423,25 @@ class RnsContext:
         L.check(L.lib().fhe_ckks_ksk_gen(self._h, ps, pp, n, _rng(seed), stream_id, _buf(kb)[0], _buf(ka)[0], mem, st), "fhe_ckks_ksk_gen")
         return kb, ka
 
+    def add_(self, a, b, n, extended=False):
+        """util/src/ring/rns.rs:254-270: a += b over [batch][limbs][n]."""
+        pa, cnt, mem, st = _buf(a)
+        limbs = self.L + self.K if extended else self.L
+        L.check(L.lib().fhe_rns_add(self._h, int(extended), pa, _buf(b)[0], n, cnt // (limbs * n), mem, st), "fhe_rns_add")
+        return a
+
+    def sub_(self, a, b, n, extended=False):
+        pa, cnt, mem, st = _buf(a)
+        limbs = self.L + self.K if extended else self.L
+        L.check(L.lib().fhe_rns_sub(self._h, int(extended), pa, _buf(b)[0], n, cnt // (limbs * n), mem, st), "fhe_rns_sub")
+        return a
+
+    def neg_(self, a, n, extended=False):
+        pa, cnt, mem, st = _buf(a)
+        limbs = self.L + self.K if extended else self.L
+        L.check(L.lib().fhe_rns_neg(self._h, int(extended), pa, n, cnt // (limbs * n), mem, st), "fhe_rns_neg")
+        return a
+
     def pk_encrypt(self, pk_b, pk_a, pt, n, batch, seed, stream_id):
         """scheme/ckks/src/ckks.rs:227-238 -> (b, a) [batch][L][n]; pk [L][n]; pt [batch][L][n] or None."""
         pb, _, mem, st = _buf(pk_b)

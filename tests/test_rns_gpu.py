@@ -641,6 +641,32 @@ def test_ckks_decrypt_mul_plain_pk_encrypt(fhe, cref, torch_cuda, log_n, bits, b
         assert 2.0 * np.sqrt(n) < first.std() < 8.0 * np.sqrt(n), first.std()              # ~ 3.2 sqrt(n/2 + 1 + n/2) in expectation
 
 
+@pytest.mark.parametrize("log_n,bits,big_l,big_k", [(6, 50, 3, 2), (13, 60, 4, 1), (15, 59, 2, 2)])
+def test_rns_add_sub_neg(fhe, cref, torch_cuda, log_n, bits, big_l, big_k):
+    """`RnsRq` +, -, unary - (util/src/ring/rns.rs:254-270; `CkksCiphertext` + / - of scheme/ckks/src/ckks.rs:322-339 `add_sub`) over qs and
+    over qs ++ ps, device and host memory: exact integers mod every limb, incl. the edge values 0 and q - 1; a - a = 0, -(-a) = a."""
+    n, batch = 1 << log_n, 3
+    primes = [int(x) for x in cref.two_adic_primes(bits, log_n + 1, big_l + big_k)]
+    qs, ps = primes[:big_l], primes[big_l:]
+    rns = fhe.RnsContext(qs, ps)
+    for ext, mods in ((False, qs), (True, qs + ps)):
+        a, b = rand_limbs(11, mods, n, batch), rand_limbs(12, mods, n, batch)
+        for l, m in enumerate(mods):
+            a[0, l, :4] = [0, m - 1, 0, m - 1]
+            b[0, l, :4] = [0, m - 1, m - 1, 0]
+        mv = np.array(mods, dtype=object)[None, :, None]
+        want_add = ((a.astype(object) + b.astype(object)) % mv).astype(np.uint64)
+        want_sub = ((a.astype(object) - b.astype(object)) % mv).astype(np.uint64)
+        want_neg = ((-a.astype(object)) % mv).astype(np.uint64)
+        assert np.array_equal(host(rns.add_(dev(torch_cuda, a), dev(torch_cuda, b), n, ext)), want_add)
+        assert np.array_equal(host(rns.sub_(dev(torch_cuda, a), dev(torch_cuda, b), n, ext)), want_sub)
+        assert np.array_equal(host(rns.neg_(dev(torch_cuda, a), n, ext)), want_neg)
+        assert np.array_equal(rns.add_(a.copy(), b, n, ext), want_add)                       # FHE_MEM_HOST
+        x = dev(torch_cuda, a)
+        assert not host(rns.sub_(x, dev(torch_cuda, a), n, ext)).any()
+        assert np.array_equal(host(rns.neg_(rns.neg_(dev(torch_cuda, a), n, ext), n, ext)), a)
+
+
 def test_ckks_ops_edge_cases(fhe, cref, torch_cuda):
     """status codes where the reference would panic or has nothing to do: empty batches, a foreign key, a one-limb base, even t"""
     import ctypes as C
