@@ -399,6 +399,19 @@ int fhe_power_up(uint64_t q, int log_b, int d, const uint64_t *in, size_t n, siz
 /* scheme/fhew/src/rlwe.rs:146-156 `Rlwe::sk_encrypt` for `batch` plaintexts (pt [batch][n] or NULL = zeros): a uniform,
  * e <- dg(3.2, 6), b = a sk + e + pt.  sk [n]: the secret key as Zq values (`Zq::from_i64` of its coefficients). */
 int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng, uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+/* rlwe.rs:237-249 `Rlwe::share_encrypt(param, a, sk, pt)`: b = a sk + e + pt for a GIVEN mask a -- what the multi-party protocol of
+ * rlwe.rs:205-324 is made of: `pk_share_gen` (pt NULL, a = the common reference string), `ksk_share_gen` / `ak_share_gen` (one row per
+ * call of the gadget), `share_decrypt` (pt NULL, a = the ciphertext's mask); the merges are fhe_rq_sum / fhe_rq_sub.  a [a_rows][n] with
+ * a_rows = rows or 1 (one polynomial shared by every row); sk [n] as Zq values; pt [rows][n] or NULL; out_b [rows][n]. */
+int fhe_rlwe_share_encrypt(const fhe_ctx *ctx, const uint64_t *a, size_t a_rows, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows,
+                           const fhe_rng *rng, uint64_t stream_id, uint64_t *out_b, fhe_mem mem, void *stream);
+/* rlwe.rs:158-170 `Rlwe::pk_encrypt`: u <- zo(0.5), e0, e1 <- dg(3.2, 6) per ciphertext; a = pk.a u + e0, b = pk.b u + e1 + pt.  pk_a, pk_b
+ * [n] (rlwe.rs:98-101 `pk_gen` = fhe_rlwe_sk_encrypt of zero, or a merged multi-party key); pt [batch][n] or NULL. */
+int fhe_rlwe_pk_encrypt(const fhe_ctx *ctx, const uint64_t *pk_a, const uint64_t *pk_b, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng,
+                        uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream);
+/* rlwe.rs:172-175 `Rlwe::decrypt`: pt = b - a sk; [batch][n]; pt may alias ct_b. */
+int fhe_rlwe_decrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t batch, uint64_t *pt,
+                     fhe_mem mem, void *stream);
 /* scheme/fhew/src/rgsw.rs:84-105 `Rgsw::sk_encrypt` of `count` plaintext polynomials (pt [count][n], `Rgsw::encode`d):
  * rows_a / rows_b [count][2d][n], the layout fhe_rgsw_prepare takes. */
 int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count,

@@ -223,6 +223,136 @@ int fhe_rlwe_sk_encrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *
     return rc;
 }
 
+// scheme/fhew/src/rlwe.rs:237-249 `Rlwe::share_encrypt(param, a, sk, pt)`: b = a sk + e + pt for a GIVEN mask a -- what `pk_share_gen`
+// (217-225: pt = 0, the common reference string as a), `ksk_share_gen` / `ak_share_gen` (276-303: one call per gadget row) and
+// `share_decrypt` (260-269: pt = 0, a = the ciphertext's mask) are made of.  a [rows][n] (or ONE polynomial shared by all rows when
+// a_rows = 1), pt [rows][n] or NULL; out_b [rows][n]
+int fhe_rlwe_share_encrypt(const fhe_ctx *ctx, const uint64_t *a, size_t a_rows, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, const fhe_rng *rng,
+                           uint64_t stream_id, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    int rc = check_ring(ctx, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || !a || (a_rows != 1 && a_rows != rows) || (!out_b && rows)) return FHE_ERR_INVALID;
+    if (rows == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t count = rows * n;
+    Mirror msk(sk, n, mem, true, st), ma(a, a_rows * n, mem, true, st), mpt(pt, pt ? count : 0, mem, true, st), mb(out_b, count, mem, false, st);
+    if (msk.rc | ma.rc | mpt.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs ws((n + count) * sizeof(u64), st);  // sk in the evaluation domain | the noise
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *sk_eval = ws.as<u64>(), *e = sk_eval + n;
+    const int log_n = ilog2(n);
+    fhe::NttIo src;
+    src.src = msk.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, sk_eval, log_n, 1, st, ctx->pm_b, src);
+    fhe::DgTable T;
+    if (rc == FHE_OK) rc = dg_table_rc(3.2, 6, &T);
+    if (rc == FHE_OK) rc = sample_dg_dev(ctx->q, T, fhe::call_key(rng, stream_id, fhe::RNG_RLWE_SHARE), 0, e, count, st);
+    if (rc == FHE_OK) {
+        fhe::NttIo sa;
+        sa.src = ma.d; sa.src_mod = (unsigned)a_rows;
+        rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, mb.d, log_n, rows, st, ctx->pm_b, sa);
+    }
+    if (rc == FHE_OK) {
+        fhe::NttIo mul;
+        mul.mul = sk_eval; mul.mul_div = (unsigned)rows; mul.mul_period = 1;
+        rc = fhe::ntt_inv_multi(ctx->d_desc, 1, mb.d, log_n, rows, st, ctx->pm_b, mul);
+    }
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::add3_kernel, dim3(grid_for(count)), dim3(256), 0, st, mb.d, (const u64 *)e, pt ? (const u64 *)mpt.d : nullptr, count, count, (u64)ctx->q);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    return rc == FHE_OK ? mb.sync_out(st) : rc;
+}
+
+// rlwe.rs:158-170 `Rlwe::pk_encrypt` for `batch` plaintexts: u <- zo(0.5), e0, e1 <- dg(3.2, 6) per ciphertext; a = pk.a u + e0,
+// b = pk.b u + e1 + pt.  pk_a, pk_b [n] (rlwe.rs:98-101 `pk_gen` = fhe_rlwe_sk_encrypt of zero, or a merged multi-party key); pt NULL = zeros
+int fhe_rlwe_pk_encrypt(const fhe_ctx *ctx, const uint64_t *pk_a, const uint64_t *pk_b, const uint64_t *pt, size_t n, size_t batch, const fhe_rng *rng,
+                        uint64_t stream_id, uint64_t *ct_a, uint64_t *ct_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    int rc = check_ring(ctx, n);
+    if (rc != FHE_OK) return rc;
+    if (!pk_a || !pk_b || ((!ct_a || !ct_b) && batch)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t count = batch * n;
+    Mirror mpa(pk_a, n, mem, true, st), mpb(pk_b, n, mem, true, st), mpt(pt, pt ? count : 0, mem, true, st), ma(ct_a, count, mem, false, st),
+        mb(ct_b, count, mem, false, st);
+    if (mpa.rc | mpb.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs ws((2 * n + 2 * count) * sizeof(u64), st);  // pk.a, pk.b in the evaluation domain | e0 | e1
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *pk_eval = ws.as<u64>(), *e = pk_eval + 2 * n;
+    const int log_n = ilog2(n);
+    const fhe::ChaChaKey K = fhe::call_key(rng, stream_id, fhe::RNG_RLWE_PK_ENC);
+    fhe::NttIo src;
+    src.src = mpa.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, pk_eval, log_n, 1, st, ctx->pm_b, src);
+    src.src = mpb.d;
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, pk_eval + n, log_n, 1, st, ctx->pm_b, src);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::sample_zo_kernel, dim3(grid_for(blocks_words(count))), dim3(256), 0, st, ma.d, count, 0.5, K, 0ull);
+    hipLaunchKernelGGL(fhe::small_i64_to_zq_kernel, dim3(grid_for(count)), dim3(256), 0, st, ma.d, count, (u64)ctx->q);
+    HIP_TRY(hipGetLastError());
+    fhe::DgTable T;
+    rc = dg_table_rc(3.2, 6, &T);
+    if (rc == FHE_OK) rc = sample_dg_dev(ctx->q, T, K, blocks_words(count), e, 2 * count, st);
+    if (rc == FHE_OK) rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, ma.d, log_n, batch, st, ctx->pm_b);  // u, once; both products read it
+    if (rc == FHE_OK && hipMemcpyAsync(mb.d, ma.d, count * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = FHE_ERR_HIP;
+    for (int half = 0; half < 2 && rc == FHE_OK; ++half) {
+        fhe::NttIo mul;
+        mul.mul = pk_eval + half * n; mul.mul_div = (unsigned)batch; mul.mul_period = 1;
+        rc = fhe::ntt_inv_multi(ctx->d_desc, 1, half ? mb.d : ma.d, log_n, batch, st, ctx->pm_b, mul);
+        if (rc != FHE_OK) break;
+        hipLaunchKernelGGL(fhe::add3_kernel, dim3(grid_for(count)), dim3(256), 0, st, half ? mb.d : ma.d, (const u64 *)(e + half * count),
+                           (half && pt) ? (const u64 *)mpt.d : nullptr, count, count, (u64)ctx->q);
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
+// rlwe.rs:172-175 `Rlwe::decrypt`: pt = b - a sk for `batch` ciphertexts; pt may alias ct_b
+int fhe_rlwe_decrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *ct_a, const uint64_t *ct_b, size_t n, size_t batch, uint64_t *pt, fhe_mem mem,
+                     void *stream) {
+    int rc = check_ring(ctx, n);
+    if (rc != FHE_OK) return rc;
+    if (!sk || ((!ct_a || !ct_b || !pt) && batch) || (batch && pt == ct_a)) return FHE_ERR_INVALID;
+    if (batch == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t count = batch * n;
+    Mirror msk(sk, n, mem, true, st), ma(ct_a, count, mem, true, st), mb(ct_b, count, mem, true, st), mo(pt, count, mem, false, st);
+    if (msk.rc | ma.rc | mb.rc | mo.rc) return FHE_ERR_HIP;
+    StreamWs ws((n + count) * sizeof(u64), st);
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *sk_eval = ws.as<u64>(), *as = sk_eval + n;
+    const int log_n = ilog2(n);
+    fhe::NttIo src;
+    src.src = msk.d; src.src_mod = 1;
+    rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, sk_eval, log_n, 1, st, ctx->pm_b, src);
+    if (rc == FHE_OK) {
+        fhe::NttIo sa;
+        sa.src = ma.d; sa.src_mod = (unsigned)batch;
+        rc = fhe::ntt_fwd_multi(ctx->d_desc, 1, as, log_n, batch, st, ctx->pm_b, sa);
+    }
+    if (rc == FHE_OK) {
+        fhe::NttIo mul;
+        mul.mul = sk_eval; mul.mul_div = (unsigned)batch; mul.mul_period = 1;
+        rc = fhe::ntt_inv_multi(ctx->d_desc, 1, as, log_n, batch, st, ctx->pm_b, mul);
+    }
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::rsub_kernel, dim3(grid_for(count)), dim3(256), 0, st, as, (const u64 *)mb.d, count, (u64)ctx->q);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mo.d, as, count * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    return mo.sync_out(st);
+}
+
 // rgsw.rs:84-105 for `count` plaintext polynomials under one secret key: rows_a / rows_b [count][2d][n]
 int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count, const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
     if (!rng) return FHE_ERR_INVALID;

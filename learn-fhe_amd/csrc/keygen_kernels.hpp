@@ -44,7 +44,7 @@ __host__ __device__ inline void chacha20_block(const ChaChaKey &K, unsigned long
 enum RngPurpose : unsigned {
     RNG_SAMPLE_UNIFORM = 1, RNG_SAMPLE_TORUS, RNG_SAMPLE_DG, RNG_SAMPLE_ZO, RNG_SAMPLE_TDG, RNG_SAMPLE_BINARY,
     RNG_RLWE_ENC, RNG_RGSW_ENC, RNG_RLWE_KSK, RNG_LWE_ENC, RNG_LWE_KSK, RNG_CKKS_ENC, RNG_CKKS_KSK,
-    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC, RNG_CKKS_PK_ENC
+    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC, RNG_CKKS_PK_ENC, RNG_RLWE_SHARE, RNG_RLWE_PK_ENC
 };
 }  // namespace fhe
 
@@ -174,6 +174,20 @@ FHE_HEADER_KERNEL void add3_kernel(u64 *__restrict__ b, const u64 *__restrict__ 
         u64 v = csub(b[i] + e[i], q);
         if (pt) v = csub(v + pt[i % pt_mod], q);
         b[i] = v;
+    }
+}
+// small two's-complement integers (zo / dg draws) as residues: `Zq::from_i64` (zq.rs:63-69) for |x| < q, in place
+FHE_HEADER_KERNEL void small_i64_to_zq_kernel(u64 *__restrict__ x, size_t count, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) {
+        const u64 v = x[i];
+        x[i] = (long long)v < 0 ? q - (0 - v) : v;
+    }
+}
+// out[i] = b[i] - out[i] mod q (rlwe.rs:172-175 `decrypt`: b - a sk)
+FHE_HEADER_KERNEL void rsub_kernel(u64 *__restrict__ out, const u64 *__restrict__ b, size_t count, u64 q) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) {
+        const u64 x = b[i], y = out[i];
+        out[i] = x >= y ? x - y : x + q - y;
     }
 }
 // out[i] += add[i] over a strided set of polynomials (rgsw.rs:101-103: `ct.0 += pt` on rows 0..d, `ct.1 += pt` on rows d..2d)

@@ -905,6 +905,32 @@ def rlwe_sk_encrypt(ctx: NttContext, sk, pt, n, batch, seed, stream_id):
     return a, b
 
 
+def rlwe_share_encrypt(ctx: NttContext, a, sk, pt, n, rows, seed, stream_id):
+    """scheme/fhew/src/rlwe.rs:237-249: b = a sk + e + pt for a given mask a ([rows][n], or [n] shared by every row) -> b [rows][n]."""
+    pa, cnt, mem, st = _buf(a)
+    pp = _buf(pt)[0] if pt is not None else None
+    b = _like(sk, (rows, n))
+    L.check(L.lib().fhe_rlwe_share_encrypt(ctx.handle, pa, cnt // n, _buf(sk)[0], pp, n, rows, _rng(seed), stream_id, _buf(b)[0], mem, st), "fhe_rlwe_share_encrypt")
+    return b
+
+
+def rlwe_pk_encrypt(ctx: NttContext, pk_a, pk_b, pt, n, batch, seed, stream_id):
+    """scheme/fhew/src/rlwe.rs:158-170 -> (a, b) [batch][n]."""
+    pa, _, mem, st = _buf(pk_a)
+    pp = _buf(pt)[0] if pt is not None else None
+    a, b = _like(pk_a, (batch, n)), _like(pk_a, (batch, n))
+    L.check(L.lib().fhe_rlwe_pk_encrypt(ctx.handle, pa, _buf(pk_b)[0], pp, n, batch, _rng(seed), stream_id, _buf(a)[0], _buf(b)[0], mem, st), "fhe_rlwe_pk_encrypt")
+    return a, b
+
+
+def rlwe_decrypt(ctx: NttContext, sk, ct_a, ct_b, n):
+    """scheme/fhew/src/rlwe.rs:172-175: b - a sk -> [batch][n]."""
+    pa, cnt, mem, st = _buf(ct_a)
+    out = _like(ct_a, (cnt // n, n))
+    L.check(L.lib().fhe_rlwe_decrypt(ctx.handle, _buf(sk)[0], pa, _buf(ct_b)[0], n, cnt // n, _buf(out)[0], mem, st), "fhe_rlwe_decrypt")
+    return out
+
+
 def rgsw_encrypt(ctx: NttContext, log_b, d, sk, pt, n, seed, stream_id):
     """scheme/fhew/src/rgsw.rs:84-105; pt [count][n] -> (rows_a, rows_b) [count][2d][n]."""
     ps, _, mem, st = _buf(sk)

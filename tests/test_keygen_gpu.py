@@ -317,3 +317,48 @@ def test_reference_tlwe_tests_decode_level(fhe, torch_cuda):
     oa, ob = fhe.tlwe_key_switch(log_b, d, ksa, ksb, ca, cb, n, n)
     assert np.array_equal(decode(host(oa).reshape(p, n), host(ob).reshape(p), s1), msgs)
     assert not np.array_equal(decode(host(oa).reshape(p, n), host(ob).reshape(p), s0), msgs)   # and no longer under sk0
+
+
+@pytest.mark.parametrize("log_n", [1, 5, 9])
+def test_reference_multi_key_encrypt_decrypt(fhe, torch_cuda, log_n):
+    """The reference's `multi_key_encrypt_decrypt` (scheme/fhew/src/rlwe.rs:434-459: three parties, q ~ 2^45, p = 16) on the device
+    entries: every party's public-key share is `share_encrypt` of zero on the common reference string a (`pk_share_gen`, rlwe.rs:217-225),
+    the merged key (a, sum of shares) encrypts (`pk_encrypt`, 158-170), every party contributes a decryption share a' s_i + e_i
+    (`share_decrypt`, 260-269) and b' minus their sum decodes to the message (`decryption_share_merge`, 271-274).  Also `Rlwe::decrypt`
+    (172-175) under the summed key, and pk_gen / pk_encrypt / decrypt of one party (rlwe.rs:345-360 `encrypt_decrypt`)."""
+    from oracle import pyref as P
+    parties, p = 3, 16
+    n = 1 << log_n
+    q = next(P.two_adic_primes(45, log_n + 1))
+    delta = q / p
+    enc = lambda m: [P.zq_from_f64(q, float(x) * delta) for x in m]  # noqa: E731
+    decd = lambda pt: [P.zq_from_f64(p, float(P.zq_to_i64(q, int(x))) / delta) for x in pt]  # noqa: E731
+    ctx = fhe.NttContext(q)
+    like = dev(torch_cuda, U([0]))
+    rnd = random.Random(60 + log_n)
+    a = fhe.sample_uniform(q, 600, 0, like, (n,))                                   # the common reference string
+    sks = [fhe.sample_dg(q, 3.2, 6, 601, i, like, (n,)) for i in range(parties)]   # rlwe.rs:94-96 `sk_gen`
+    shares = torch_cuda.stack([fhe.rlwe_share_encrypt(ctx, a, sk, None, n, 1, 602, i)[0] for i, sk in enumerate(sks)])
+    pk_b = fhe.rq_sum(q, shares.contiguous(), n)                                    # `pk_share_merge`: (a, sum of the shares)
+    batch = 4
+    msgs = [[rnd.randrange(p) for _ in range(n)] for _ in range(batch)]
+    ca, cb = fhe.rlwe_pk_encrypt(ctx, a, pk_b, dev(torch_cuda, U([enc(m) for m in msgs])), n, batch, 603, 0)
+    assert not np.array_equal(host(ca)[0], host(ca)[1])                             # a fresh u per ciphertext
+    dsh = torch_cuda.stack([fhe.rlwe_share_encrypt(ctx, ca, sk, None, n, batch, 604, i) for i, sk in enumerate(sks)])   # [parties][batch][n]
+    for c in range(batch):
+        tot = fhe.rq_sum(q, dsh[:, c].contiguous(), n)
+        pt = (host(cb)[c].astype(object) - host(tot).astype(object)) % q            # b - sum of the shares
+        assert decd(pt) == msgs[c], c
+    # the same through Rlwe::decrypt under the summed key (no fresh decryption noise)
+    sk_sum = fhe.rq_sum(q, torch_cuda.stack(sks).contiguous(), n)
+    pts = host(fhe.rlwe_decrypt(ctx, sk_sum, ca, cb, n))
+    for c in range(batch):
+        assert decd(L(pts[c])) == msgs[c], c
+    # one party alone: pk_gen (an encryption of zero), pk_encrypt, decrypt in place of ct_b
+    za, zb = fhe.rlwe_sk_encrypt(ctx, sks[0], None, n, 1, 605, 0)
+    ea, eb = fhe.rlwe_pk_encrypt(ctx, za[0].contiguous(), zb[0].contiguous(), dev(torch_cuda, U([enc(m) for m in msgs])), n, batch, 606, 0)
+    one = host(fhe.rlwe_decrypt(ctx, sks[0], ea, eb, n))
+    for c in range(batch):
+        assert decd(L(one[c])) == msgs[c], c
+    noise = [P.zq_to_i64(q, (int(x) - y) % q) for x, y in zip(one[0], enc(msgs[0]))]
+    assert 0 < max(abs(v) for v in noise) <= 19 * 19 * n + 19 + 19 * n                  # e u + e1 + e0 s with |e|, |s| <= 19, |u| <= 1
