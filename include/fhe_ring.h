@@ -416,6 +416,10 @@ int fhe_rlwe_decrypt(const fhe_ctx *ctx, const uint64_t *sk, const uint64_t *ct_
  * rows_a / rows_b [count][2d][n], the layout fhe_rgsw_prepare takes. */
 int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, const uint64_t *pt, size_t n, size_t count,
                      const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
+/* rgsw.rs:75-83 `Rgsw::pk_encrypt`: as fhe_rgsw_encrypt with the 2d encryptions of zero made by fhe_rlwe_pk_encrypt (what the reference's
+ * RGSW tests encrypt with; `Bootstrapping::key_share_gen`, bootstrapping.rs:277-283, under the merged public key). */
+int fhe_rgsw_pk_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *pk_a, const uint64_t *pk_b, const uint64_t *pt, size_t n, size_t count,
+                        const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream);
 /* scheme/fhew/src/rlwe.rs:109-120 `Rlwe::ksk_gen(param, sk0, sk1)` (t = 0) and 122-132 `Rlwe::ak_gen(param, t, sk0)` (t != 0,
  * sk1 ignored: the key switches sk0(X^t) back to sk0): rows_a / rows_b [d][n], the layout fhe_ksk_prepare takes. */
 int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n,

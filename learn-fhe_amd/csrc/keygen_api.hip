@@ -391,6 +391,43 @@ int fhe_rgsw_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk, c
     return rc;
 }
 
+// rgsw.rs:75-83 `Rgsw::pk_encrypt` (84-105 with `Either::Right(pk)`): 2d public-key encryptions of zero per plaintext, then the gadget
+// terms as in fhe_rgsw_encrypt -- what the reference's RGSW tests encrypt with, and how `Bootstrapping::key_share_gen`
+// (bootstrapping.rs:277-283) makes a party's blind-rotation key rows under the merged public key.  rows_a / rows_b [count][2d][n]
+int fhe_rgsw_pk_encrypt(const fhe_ctx *ctx, int log_b, int d, const uint64_t *pk_a, const uint64_t *pk_b, const uint64_t *pt, size_t n, size_t count,
+                        const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    int rc = check_ring(ctx, n), rb = 0;
+    if (rc == FHE_OK) rc = gadget_geometry(ctx->q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if (!pk_a || !pk_b || ((!pt || !rows_a || !rows_b) && count)) return FHE_ERR_INVALID;
+    if (count == 0) return FHE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return FHE_ERR_HIP;
+    const size_t rows = count * 2 * d;
+    Mirror mpa(pk_a, n, mem, true, st), mpb(pk_b, n, mem, true, st), mpt(pt, n * count, mem, true, st), ma(rows_a, rows * n, mem, false, st),
+        mb(rows_b, rows * n, mem, false, st);
+    if (mpa.rc | mpb.rc | mpt.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    StreamWs ws(count * d * n * sizeof(u64), st);  // power_up(pt): [count][d][n]
+    if (ws.rc != FHE_OK) return ws.rc;
+    u64 *pw = ws.as<u64>();
+    rc = fhe_rlwe_pk_encrypt(ctx, (const uint64_t *)mpa.d, (const uint64_t *)mpb.d, nullptr, n, rows, rng, stream_id, (uint64_t *)ma.d, (uint64_t *)mb.d, FHE_MEM_DEVICE,
+                             stream);
+    if (rc == FHE_OK) {
+        hipLaunchKernelGGL(fhe::power_up_kernel, dim3(grid_for(n * count * d)), dim3(256), 0, st, (const u64 *)mpt.d, pw, n, count, d, rb, log_b,
+                           fhe::make_barrett(ctx->q), 0);
+        for (size_t c = 0; c < count; ++c) {
+            hipLaunchKernelGGL(fhe::add_assign_kernel, dim3(grid_for(d * n)), dim3(256), 0, st, ma.d + c * 2 * d * n, (const u64 *)(pw + c * d * n), (size_t)d * n, (u64)ctx->q);
+            hipLaunchKernelGGL(fhe::add_assign_kernel, dim3(grid_for(d * n)), dim3(256), 0, st, mb.d + (c * 2 * d + d) * n, (const u64 *)(pw + c * d * n), (size_t)d * n, (u64)ctx->q);
+        }
+        if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
+    }
+    if (rc == FHE_OK) rc = ma.sync_out(st);
+    if (rc == FHE_OK) rc = mb.sync_out(st);
+    return rc;
+}
+
 // rlwe.rs:109-132: key-switching key sk1 -> sk0 (rows encrypt -sk1 base_j under sk0); t != 0: automorphism key, sk1 = sk0(X^t)
 int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, const uint64_t *sk1, int64_t t, size_t n, const fhe_rng *rng, uint64_t stream_id, uint64_t *rows_a, uint64_t *rows_b, fhe_mem mem, void *stream) {
     if (!rng) return FHE_ERR_INVALID;

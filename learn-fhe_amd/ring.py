@@ -905,6 +905,17 @@ def rlwe_sk_encrypt(ctx: NttContext, sk, pt, n, batch, seed, stream_id):
     return a, b
 
 
+def rgsw_pk_encrypt(ctx: NttContext, log_b, d, pk_a, pk_b, pt, n, seed, stream_id):
+    """scheme/fhew/src/rgsw.rs:75-83; pt [count][n] -> (rows_a, rows_b) [count][2d][n]."""
+    pa, _, mem, st = _buf(pk_a)
+    pp, cnt, _, _ = _buf(pt)
+    count = cnt // n
+    ra, rb = _like(pk_a, (count, 2 * d, n)), _like(pk_a, (count, 2 * d, n))
+    L.check(L.lib().fhe_rgsw_pk_encrypt(ctx.handle, log_b, d, pa, _buf(pk_b)[0], pp, n, count, _rng(seed), stream_id, _buf(ra)[0], _buf(rb)[0], mem, st),
+            "fhe_rgsw_pk_encrypt")
+    return ra, rb
+
+
 def rlwe_share_encrypt(ctx: NttContext, a, sk, pt, n, rows, seed, stream_id):
     """scheme/fhew/src/rlwe.rs:237-249: b = a sk + e + pt for a given mask a ([rows][n], or [n] shared by every row) -> b [rows][n]."""
     pa, cnt, mem, st = _buf(a)

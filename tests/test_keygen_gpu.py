@@ -362,3 +362,38 @@ def test_reference_multi_key_encrypt_decrypt(fhe, torch_cuda, log_n):
         assert decd(L(one[c])) == msgs[c], c
     noise = [P.zq_to_i64(q, (int(x) - y) % q) for x, y in zip(one[0], enc(msgs[0]))]
     assert 0 < max(abs(v) for v in noise) <= 19 * 19 * n + 19 + 19 * n                  # e u + e1 + e0 s with |e|, |s| <= 19, |u| <= 1
+
+
+def test_reference_rgsw_tests_with_public_key_encryption(fhe, torch_cuda):
+    """The reference's RGSW tests encrypt with the PUBLIC key (scheme/fhew/src/rgsw.rs:162-230: `key_gen`, `pk_encrypt`): `external_product`
+    (198-211: RGSW_pk(m0) x RLWE_pk(m1) decrypts to m0 m1) and `internal_product` (214-230: RGSW_pk(m0) x RGSW_pk(m1), then the external
+    product of the result with an encryption of 1... here: with RLWE_pk(m2), decrypting to m0 m1 m2) -- keys and ciphertexts from
+    fhe_rlwe_sk_encrypt (pk_gen), fhe_rlwe_pk_encrypt, fhe_rgsw_pk_encrypt, decrypted by fhe_rlwe_decrypt."""
+    from oracle import pyref as P
+    rnd = random.Random(71)
+    log_n, p, log_b, d = 7, 16, 5, 9
+    n = 1 << log_n
+    q = next(P.two_adic_primes(45, log_n + 1))
+    delta = q / p
+    enc = lambda m: [P.zq_from_f64(q, float(x) * delta) for x in m]  # noqa: E731
+    decd = lambda pt: [P.zq_from_f64(p, float(P.zq_to_i64(q, int(x))) / delta) for x in pt]  # noqa: E731
+    ctx = fhe.NttContext(q)
+    like = dev(torch_cuda, U([0]))
+    sk = fhe.sample_dg(q, 3.2, 6, 700, 0, like, (n,))
+    za, zb = fhe.rlwe_sk_encrypt(ctx, sk, None, n, 1, 701, 0)                       # rgsw.rs:50-52 `key_gen`: pk = an encryption of zero
+    pk_a, pk_b = za[0].contiguous(), zb[0].contiguous()
+    m0, m1, m2 = ([rnd.randrange(2) for _ in range(n)] for _ in range(3))           # small messages: the products stay below p
+    m0 = [0] * n; m0[3] = 1                                                         # a monomial, as the blind rotation's RGSW messages are
+    ra, rb = fhe.rgsw_pk_encrypt(ctx, log_b, d, pk_a, pk_b, dev(torch_cuda, U([m0, m1])), n, 702, 0)
+    key = fhe.GadgetKey(ctx, log_b, d, ra, rb, n, rgsw=True)
+    ca, cb = fhe.rlwe_pk_encrypt(ctx, pk_a, pk_b, dev(torch_cuda, U([enc(m1), enc(m2)])), n, 2, 703, 0)
+    a, b = ca[:1].clone(), cb[:1].clone()
+    key.external_product_(0, a, b)                                                  # RGSW(m0) x RLWE(m1)
+    assert decd(L(host(fhe.rlwe_decrypt(ctx, sk, a, b, n)))) == P.nega_cyclic_schoolbook_mul(p, m0, m1)
+    rows_a, rows_b = ra[1:2].clone(), rb[1:2].clone()                               # RGSW(m0) x RGSW(m1) -> RGSW(m0 m1) (rgsw.rs:130-150)
+    key.internal_product_(0, rows_a, rows_b)
+    prod = fhe.GadgetKey(ctx, log_b, d, rows_a, rows_b, n, rgsw=True)
+    a, b = ca[1:2].clone(), cb[1:2].clone()
+    prod.external_product_(0, a, b)
+    want = P.nega_cyclic_schoolbook_mul(p, P.nega_cyclic_schoolbook_mul(p, m0, m1), m2)
+    assert decd(L(host(fhe.rlwe_decrypt(ctx, sk, a, b, n)))) == want
