@@ -431,6 +431,14 @@ int fhe_lwe_sk_encrypt(uint64_t q, const uint64_t *sk, const uint64_t *pt, size_
 /* scheme/fhew/src/lwe.rs:108-119 `Lwe::ksk_gen(param, sk0, sk1)`: ksk_a [n1 d][n0], ksk_b [n1 d] (digit-major rows), the layout
  * fhe_lwe_key_switch / fhe_fhew_bootstrap take with n_in = n1, n_out = n0. */
 int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, const fhe_rng *rng, uint64_t stream_id, uint64_t *ksk_a, uint64_t *ksk_b, fhe_mem mem, void *stream);
+/* lwe.rs:169-183 `Lwe::sk_share_encrypt(param, a, sk, pt)` / 197-207 `share_decrypt` (pt NULL): b[r] = <a[r], sk> + pt[r] + e[r] for GIVEN
+ * masks a [rows][n] (a common reference string, or a ciphertext's mask); the merges (lwe.rs:185-195, 209-212) are sums (fhe_rq_sum). */
+int fhe_lwe_share_encrypt(uint64_t q, const uint64_t *a, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, const fhe_rng *rng,
+                          uint64_t stream_id, uint64_t *out_b, fhe_mem mem, void *stream);
+/* lwe.rs:214-226 `Lwe::ksk_share_gen(param, crs, sk0, sk1)`: crs [n1 d][n0] is the ksk_a every party (and the merged key) uses; out_b [n1 d];
+ * the merged key-switching key is (crs, fhe_rq_sum of the shares) (lwe.rs:228-237). */
+int fhe_lwe_ksk_share_gen(uint64_t q, int log_b, int d, const uint64_t *crs, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1,
+                          const fhe_rng *rng, uint64_t stream_id, uint64_t *out_b, fhe_mem mem, void *stream);
 /* util/src/ring.rs:328-341 `Rq: Sum`: out[i] = sum_k in[k][i] mod q, in [count][len] (callers used to loop fhe_rq_add) */
 int fhe_rq_sum(uint64_t q, const uint64_t *in, size_t len, size_t count, uint64_t *out, fhe_mem mem, void *stream);
 /* ---- CKKS key material (scheme/ckks/src/ckks.rs:139-183, 215-225).  Secret keys are two's-complement i64 vectors. */

@@ -11,6 +11,6 @@ from .ring import (BootstrapKey, CkksKey, CkksShard, Fhew, GadgetKey, NttContext
                    power_up, rgsw_encrypt, rlwe_ksk_gen, rlwe_sk_encrypt, sample_dg, sample_torus, sample_uniform,
                    lwe_ksk_gen, lwe_sk_encrypt, rq_sum,
                    sample_binary, sample_tdg, sample_zo, tggsw_encrypt, tglwe_sk_encrypt, tlwe_ksk_gen, tlwe_sk_encrypt,
-                   rlwe_share_encrypt, rlwe_pk_encrypt, rlwe_decrypt, rgsw_pk_encrypt,
+                   rlwe_share_encrypt, rlwe_pk_encrypt, rlwe_decrypt, rgsw_pk_encrypt, lwe_share_encrypt, lwe_ksk_share_gen,
                    TggswKeyK, tglwek_rotate, tglwek_sample_extract, tglwek_sk_encrypt, tggswk_encrypt,
                    Rng, STREAM_AUTO, chacha20_block)

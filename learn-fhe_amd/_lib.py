@@ -166,6 +166,8 @@ def lib():
         L.fhe_rlwe_pk_encrypt.argtypes = [vp, vp, vp, vp, sz, sz, vp, u64, vp, vp, ci, vp]
         L.fhe_rlwe_decrypt.argtypes = [vp, vp, vp, vp, sz, sz, vp, ci, vp]
         L.fhe_rgsw_pk_encrypt.argtypes = [vp, ci, ci, vp, vp, vp, sz, sz, vp, u64, vp, vp, ci, vp]
+        L.fhe_lwe_share_encrypt.argtypes = [u64, vp, vp, vp, sz, sz, vp, u64, vp, ci, vp]
+        L.fhe_lwe_ksk_share_gen.argtypes = [u64, ci, ci, vp, vp, sz, vp, sz, vp, u64, vp, ci, vp]
         L.fhe_rns_add.argtypes = [vp, ci, vp, vp, sz, sz, ci, vp]
         L.fhe_rns_sub.argtypes = [vp, ci, vp, vp, sz, sz, ci, vp]
         L.fhe_rns_neg.argtypes = [vp, ci, vp, sz, sz, ci, vp]

@@ -460,18 +460,20 @@ int fhe_rlwe_ksk_gen(const fhe_ctx *ctx, int log_b, int d, const uint64_t *sk0, 
 }
 
 // scheme/fhew/src/lwe.rs:128-139 for `rows` plaintexts (pt [rows] or NULL = zeros): out_a [rows][n] uniform, out_b [rows]
+// a_given: the masks come from the caller (the multi-party shares of lwe.rs:169-226: a common reference string, or a ciphertext's
+// mask) and out_a is not written
 static int lwe_encrypt_common(uint64_t q, const u64 *sk, const u64 *pt, const u64 *sk1, size_t n1, int rb, int log_b, size_t n, size_t rows,
-                              const fhe::ChaChaKey &K, u64 *out_a, u64 *out_b, hipStream_t st) {
+                              const fhe::ChaChaKey &K, u64 *out_a, u64 *out_b, hipStream_t st, const u64 *a_given = nullptr) {
     fhe::DgTable T;
     int rc = dg_table_rc(3.2, 6, &T);
     if (rc != FHE_OK) return rc;
     StreamWs we(rows * sizeof(u64), st);
     if (we.rc != FHE_OK) return we.rc;
-    rc = sample_uniform_dev(q, K, 0, out_a, rows * n, st);
+    if (!a_given) rc = sample_uniform_dev(q, K, 0, out_a, rows * n, st);
     if (rc == FHE_OK) rc = sample_dg_dev(q, T, K, blocks_uniform(rows * n), we.as<u64>(), rows, st);
     if (rc == FHE_OK) {
-        hipLaunchKernelGGL(fhe::lwe_encrypt_kernel, dim3(grid_for(rows)), dim3(256), 0, st, (const u64 *)out_a, sk, (const u64 *)we.as<u64>(), pt, out_b, n, rows,
-                           fhe::make_barrett(q), sk1, n1 ? n1 : 1, rb, log_b);
+        hipLaunchKernelGGL(fhe::lwe_encrypt_kernel, dim3(grid_for(rows)), dim3(256), 0, st, a_given ? a_given : (const u64 *)out_a, sk, (const u64 *)we.as<u64>(), pt,
+                           out_b, n, rows, fhe::make_barrett(q), sk1, n1 ? n1 : 1, rb, log_b);
         if (hipGetLastError() != hipSuccess) rc = FHE_ERR_HIP;
     }
     return rc;
@@ -511,6 +513,41 @@ int fhe_lwe_ksk_gen(uint64_t q, int log_b, int d, const uint64_t *sk0, size_t n0
     if (rc == FHE_OK) rc = ma.sync_out(st);
     if (rc == FHE_OK) rc = mb.sync_out(st);
     return rc;
+}
+
+// scheme/fhew/src/lwe.rs:169-183 `Lwe::sk_share_encrypt(param, a, sk, pt)` and 197-207 `share_decrypt` (pt NULL): b[r] = <a[r], sk> + pt[r] +
+// e[r] for GIVEN masks a [rows][n]; the merges (185-195, 209-212) are sums: fhe_rq_sum / fhe_rq_sub with len = 1 ... or on the host
+int fhe_lwe_share_encrypt(uint64_t q, const uint64_t *a, const uint64_t *sk, const uint64_t *pt, size_t n, size_t rows, const fhe_rng *rng, uint64_t stream_id,
+                          uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    if (q < 2 || (q >> 62) || !sk || !a || n == 0 || (!out_b && rows)) return FHE_ERR_INVALID;
+    if (rows == 0) return FHE_OK;
+    PtrDeviceGuard pguard(out_b, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    Mirror msk(sk, n, mem, true, st), ma(a, rows * n, mem, true, st), mpt(pt, pt ? rows : 0, mem, true, st), mb(out_b, rows, mem, false, st);
+    if (msk.rc | ma.rc | mpt.rc | mb.rc) return FHE_ERR_HIP;
+    int rc = lwe_encrypt_common(q, msk.d, pt ? mpt.d : nullptr, nullptr, 0, 0, 0, n, rows, fhe::call_key(rng, stream_id, fhe::RNG_LWE_SHARE), nullptr, mb.d, st, ma.d);
+    return rc == FHE_OK ? mb.sync_out(st) : rc;
+}
+
+// lwe.rs:214-226 `Lwe::ksk_share_gen(param, crs, sk0, sk1)`: row r = j n1 + i: b = <crs[r], sk0> - sk1[i] base_j + e.  crs [n1 d][n0] (the
+// common reference string: the ksk_a every party and the merged key share), out_b [n1 d]; the merged key is (crs, sum of the shares)
+int fhe_lwe_ksk_share_gen(uint64_t q, int log_b, int d, const uint64_t *crs, const uint64_t *sk0, size_t n0, const uint64_t *sk1, size_t n1, const fhe_rng *rng,
+                          uint64_t stream_id, uint64_t *out_b, fhe_mem mem, void *stream) {
+    if (!rng) return FHE_ERR_INVALID;
+    int rb = 0;
+    int rc = gadget_geometry(q, log_b, d, &rb);
+    if (rc != FHE_OK) return rc;
+    if ((q >> 62) || !crs || !sk0 || !sk1 || n0 == 0 || n1 == 0 || !out_b) return FHE_ERR_INVALID;
+    PtrDeviceGuard pguard(out_b, mem);
+    if (!pguard.ok) return FHE_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = n1 * d;
+    Mirror m0(sk0, n0, mem, true, st), m1(sk1, n1, mem, true, st), ma(crs, rows * n0, mem, true, st), mb(out_b, rows, mem, false, st);
+    if (m0.rc | m1.rc | ma.rc | mb.rc) return FHE_ERR_HIP;
+    rc = lwe_encrypt_common(q, m0.d, nullptr, m1.d, n1, rb, log_b, n0, rows, fhe::call_key(rng, stream_id, fhe::RNG_LWE_KSK_SHARE), nullptr, mb.d, st, ma.d);
+    return rc == FHE_OK ? mb.sync_out(st) : rc;
 }
 
 // util/src/ring.rs:328-341 `Rq: Sum` over `count` polynomials of `len` coefficients: in [count][len] -> out [len]

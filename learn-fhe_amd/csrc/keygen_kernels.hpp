@@ -44,7 +44,7 @@ __host__ __device__ inline void chacha20_block(const ChaChaKey &K, unsigned long
 enum RngPurpose : unsigned {
     RNG_SAMPLE_UNIFORM = 1, RNG_SAMPLE_TORUS, RNG_SAMPLE_DG, RNG_SAMPLE_ZO, RNG_SAMPLE_TDG, RNG_SAMPLE_BINARY,
     RNG_RLWE_ENC, RNG_RGSW_ENC, RNG_RLWE_KSK, RNG_LWE_ENC, RNG_LWE_KSK, RNG_CKKS_ENC, RNG_CKKS_KSK,
-    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC, RNG_CKKS_PK_ENC, RNG_RLWE_SHARE, RNG_RLWE_PK_ENC
+    RNG_TLWE_ENC, RNG_TLWE_KSK, RNG_TGLWE_ENC, RNG_TGGSW_ENC, RNG_TGLWEK_ENC, RNG_TGGSWK_ENC, RNG_CKKS_PK_ENC, RNG_RLWE_SHARE, RNG_RLWE_PK_ENC, RNG_LWE_SHARE, RNG_LWE_KSK_SHARE
 };
 }  // namespace fhe
 

@@ -905,6 +905,26 @@ def rlwe_sk_encrypt(ctx: NttContext, sk, pt, n, batch, seed, stream_id):
     return a, b
 
 
+def lwe_share_encrypt(q, a, sk, pt, n, seed, stream_id):
+    """scheme/fhew/src/lwe.rs:169-183 / 197-207: b[r] = <a[r], sk> + pt[r] + e[r] for given masks a [rows][n] -> b [rows]."""
+    pa, cnt, mem, st = _buf(a)
+    rows = cnt // n
+    pp = _buf(pt)[0] if pt is not None else None
+    b = _like(a, (rows,))
+    L.check(L.lib().fhe_lwe_share_encrypt(q, pa, _buf(sk)[0], pp, n, rows, _rng(seed), stream_id, _buf(b)[0], mem, st), "fhe_lwe_share_encrypt")
+    return b
+
+
+def lwe_ksk_share_gen(q, log_b, d, crs, sk0, sk1, seed, stream_id):
+    """scheme/fhew/src/lwe.rs:214-226: crs [n1 d][n0] -> b [n1 d]."""
+    pc, _, mem, st = _buf(crs)
+    p0, n0, _, _ = _buf(sk0)
+    p1, n1, _, _ = _buf(sk1)
+    b = _like(crs, (n1 * d,))
+    L.check(L.lib().fhe_lwe_ksk_share_gen(q, log_b, d, pc, p0, n0, p1, n1, _rng(seed), stream_id, _buf(b)[0], mem, st), "fhe_lwe_ksk_share_gen")
+    return b
+
+
 def rgsw_pk_encrypt(ctx: NttContext, log_b, d, pk_a, pk_b, pt, n, seed, stream_id):
     """scheme/fhew/src/rgsw.rs:75-83; pt [count][n] -> (rows_a, rows_b) [count][2d][n]."""
     pa, _, mem, st = _buf(pk_a)

@@ -397,3 +397,95 @@ def test_reference_rgsw_tests_with_public_key_encryption(fhe, torch_cuda):
     prod.external_product_(0, a, b)
     want = P.nega_cyclic_schoolbook_mul(p, P.nega_cyclic_schoolbook_mul(p, m0, m1), m2)
     assert decd(L(host(fhe.rlwe_decrypt(ctx, sk, a, b, n)))) == want
+
+
+def test_reference_multi_key_gates(fhe, torch_cuda):
+    """The reference's `multi_key_op` (scheme/fhew/src/fhew/boolean.rs:337-386) at ITS `multi_key_testing_param` (q ~ 2^54, N = 512, base 2^6 x 9,
+    LWE n = 100 over 2^16 with (4, 4), w = 10, p = 4) with THREE parties, every share and every merge on the device entries:
+    `Bootstrapping::crs_gen` (bootstrapping.rs:256-273) = uniform draws; `Rlwe::pk_share_gen` / `pk_share_merge` (rlwe.rs:217-235);
+    `key_share_gen` (bootstrapping.rs:275-298): a fresh LWE key per party, `Lwe::ksk_share_gen` on the common masks (lwe.rs:214-226),
+    brk rows = `Rgsw::pk_encrypt(X^{s_j})` under the merged public key, `Rlwe::ak_share_gen` per automorphism (rlwe.rs:305-314) =
+    share_encrypt of power_up(-z(X^t)); `key_share_merge` (300-320): sums of the shares and `Rgsw::internal_product` across the parties;
+    inputs `FhewBool::pk_encrypt` (boolean.rs:31-40: public-key RLWE encryption of the constant, sample_extract(0)); outputs decrypted by
+    `share_decrypt` / `decryption_share_merge` (lwe.rs:197-212).  Gates not / and / nand / or / nor / xor / xnor / majority over all inputs."""
+    from oracle import pyref as P
+    parties, p = 3, 4
+    log_q, log_n, log_b, d, w = 54, 9, 6, 9, 10
+    n_lwe, q_ks, kb, kd = 100, 1 << 16, 4, 4
+    n = 1 << log_n
+    q = next(P.two_adic_primes(log_q, log_n + 1))
+    ctx = fhe.NttContext(q)
+    like = dev(torch_cuda, U([0]))
+    ts = P.ak_t(n, w)
+    zq = lambda v, m: dev(torch_cuda, U([int(x) % m for x in v]))  # noqa: E731
+    # common reference string
+    crs_pk = fhe.sample_uniform(q, 800, 0, like, (n,))
+    crs_ksk = fhe.sample_uniform(q_ks, 800, 1, like, (n * kd, n_lwe))
+    crs_ak = fhe.sample_uniform(q, 800, 2, like, (len(ts), d, n))
+    # the parties' ring keys and the merged public key
+    z_i = [host(fhe.sample_dg(0, 3.2, 6, 801, i, like, (n,))).view(np.int64) for i in range(parties)]
+    z_q = [zq(z, q) for z in z_i]
+    pk_b = fhe.rq_sum(q, torch_cuda.stack([fhe.rlwe_share_encrypt(ctx, crs_pk, z_q[i], None, n, 1, 802, i)[0] for i in range(parties)]).contiguous(), n)
+    # bootstrapping-key shares
+    ksk_shares, brk_rows, ak_shares = [], [], []
+    for i in range(parties):
+        s = host(fhe.sample_dg(0, 3.2, 6, 803, i, like, (n_lwe,))).view(np.int64)      # the party's own LWE key
+        ksk_shares.append(fhe.lwe_ksk_share_gen(q_ks, kb, kd, crs_ksk, zq(s, q_ks), zq(z_i[i], q_ks), 804, i))
+        mono = np.zeros((n_lwe, n), dtype=np.uint64)
+        for j, sj in enumerate(s):
+            e = int(sj) % (2 * n)
+            mono[j, e % n] = 1 if e < n else q - 1
+        brk_rows.append(fhe.rgsw_pk_encrypt(ctx, log_b, d, crs_pk, pk_b, dev(torch_cuda, mono), n, 805, i))
+        shares_t = []
+        for ti, t in enumerate(ts):
+            z_auto = fhe.automorphism(q, t, z_q[i].reshape(1, n), n)
+            pt = fhe.power_up(q, log_b, d, fhe.rq_neg(q, z_auto), n).reshape(d, n).contiguous()   # power_up(-z(X^t)) (rlwe.rs:283)
+            shares_t.append(fhe.rlwe_share_encrypt(ctx, crs_ak[ti].contiguous(), z_q[i], pt, n, d, 806, i * 100 + ti))
+        ak_shares.append(torch_cuda.stack(shares_t))                                         # [|ts|][d][n]
+    # merge
+    ksk_b = fhe.rq_sum(q_ks, torch_cuda.stack(ksk_shares).contiguous(), n * kd)
+    acc_a, acc_b = brk_rows[0]
+    for i in range(1, parties):                                                              # reduce(|acc, item| internal_product(acc, item))
+        key = fhe.GadgetKey(ctx, log_b, d, acc_a, acc_b, n, rgsw=True)
+        nxt_a, nxt_b = brk_rows[i][0].clone(), brk_rows[i][1].clone()
+        for j in range(n_lwe):
+            key.internal_product_(j, nxt_a[j:j + 1], nxt_b[j:j + 1])
+        acc_a, acc_b = nxt_a, nxt_b
+    ak_b = torch_cuda.stack([fhe.rq_sum(q, torch_cuda.stack([ak_shares[i][ti] for i in range(parties)]).contiguous(), d * n).reshape(d, n)
+                             for ti in range(len(ts))]).contiguous()
+    bk = fhe.BootstrapKey(ctx, fhe.GadgetKey(ctx, log_b, d, acc_a, acc_b, n, rgsw=True), fhe.GadgetKey(ctx, log_b, d, crs_ak.contiguous(), ak_b, n, rgsw=False), ts, w)
+    ev = fhe.Fhew(bk, q_ks, kb, kd, crs_ksk, ksk_b)
+    delta = q / float(p)
+    stream = [0]
+
+    def encrypt(bits):  # FhewBool::pk_encrypt
+        stream[0] += 1
+        pt = np.zeros((len(bits), n), dtype=np.uint64)
+        pt[:, 0] = [P.zq_from_f64(q, float(m) * delta) for m in bits]
+        ca, cb = fhe.rlwe_pk_encrypt(ctx, crs_pk, pk_b, dev(torch_cuda, pt), n, len(bits), 807, stream[0])
+        return fhe.rlwe_sample_extract(q, ca, cb, n, 0)
+
+    def decrypt(ct):    # share_decrypt per party, decryption_share_merge, Fhew::decode
+        stream[0] += 1
+        a, b = ct
+        shares = torch_cuda.stack([fhe.lwe_share_encrypt(q, a.reshape(-1, n).contiguous(), z_q[i], None, n, 808, stream[0] * 10 + i) for i in range(parties)])
+        tot = fhe.rq_sum(q, shares.contiguous(), shares.shape[1])
+        out = []
+        for bv, sv in zip(L(host(b)), L(host(tot))):
+            m = P.zq_from_f64(p, float(P.zq_to_i64(q, (bv - sv) % q)) / delta)
+            assert m in (0, 1), m
+            out.append(m)
+        return out
+
+    bit = lambda k: [(m >> k) & 1 for m in range(8)]  # noqa: E731
+    m0, m1, m2 = bit(0), bit(1), bit(2)
+    c0, c1, c2 = encrypt(m0), encrypt(m1), encrypt(m2)
+    assert decrypt(c0) == m0 and decrypt(c2) == m2
+    assert decrypt(ev.not_(c0)) == [1 - x for x in m0]
+    assert decrypt(ev.and_(c0, c1)) == [x & y for x, y in zip(m0, m1)]
+    assert decrypt(ev.nand(c0, c1)) == [1 - (x & y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.or_(c0, c1)) == [x | y for x, y in zip(m0, m1)]
+    assert decrypt(ev.nor(c0, c1)) == [1 - (x | y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.xor(c0, c1)) == [x ^ y for x, y in zip(m0, m1)]
+    assert decrypt(ev.xnor(c0, c1)) == [1 - (x ^ y) for x, y in zip(m0, m1)]
+    assert decrypt(ev.majority(c0, c1, c2)) == [(x & y) | (y & z) | (z & x) for x, y, z in zip(m0, m1, m2)]
