@@ -189,6 +189,24 @@ def test_whole_bootstrapping_key_made_on_the_device(fhe, torch_cuda):
     assert decrypt(ev.or_(c0, c1)) == [x | y for x, y in zip(m0, m1)]
     assert decrypt(ev.xor(c0, c1)) == [x ^ y for x, y in zip(m0, m1)]
     assert decrypt(ev.xor(ev.nand(c0, c1), ev.or_(c0, c1))) == [(1 - (x & y)) ^ (x | y) for x, y in zip(m0, m1)]
+    # `FhewU8::wrapping_add` (fhew/uint8.rs:65-90, its `op` test 306-340): a ripple adder of `FhewBool::overflowing_add` / `carrying_add`
+    # (fhew/boolean.rs:139-150: t = a ^ b, sum = t ^ c, carry = (a & b) | (t & c)) -- 37 gate bootstraps in sequence on 12 pairs of bytes
+    rnd = random.Random(9)
+    xs, ys = [rnd.randrange(256) for _ in range(12)], [rnd.randrange(256) for _ in range(12)]
+    xs[0], ys[0], xs[1], ys[1] = 255, 1, 255, 255
+    xb, yb = [encrypt([(x >> i) & 1 for x in xs]) for i in range(8)], [encrypt([(y >> i) & 1 for y in ys]) for i in range(8)]
+    out_bits, carry = [], None
+    for i in range(8):
+        t = ev.xor(xb[i], yb[i])
+        if carry is None:
+            out_bits.append(t)
+            carry = ev.and_(xb[i], yb[i])
+        else:
+            out_bits.append(ev.xor(t, carry))
+            if i < 7:
+                carry = ev.or_(ev.and_(xb[i], yb[i]), ev.and_(t, carry))
+    got = [sum(b << i for i, b in enumerate(bits)) for bits in zip(*[decrypt(c) for c in out_bits])]
+    assert got == [(x + y) & 255 for x, y in zip(xs, ys)]
 
 
 def test_rq_sum(fhe, torch_cuda):
